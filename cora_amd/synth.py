@@ -1,0 +1,164 @@
+"""Deterministic synthetic reference genomes, FASTA/.fai writers and split files.
+
+No real genome exists offline, so every workload and fixture is a seeded
+synthetic genome.  Generation uses numpy's
+frozen legacy ``RandomState`` so the bytes are stable across numpy versions.
+
+The FASTA layout is the one the reference's loader assumes
+(/root/reference/homTable_setup.cpp:96-202): a fixed line width, ``\\n`` line
+ends; the ``.fai`` has the five columns ``cora faiGenerate`` writes
+(/root/reference/cora.cpp:1023).
+"""
+from __future__ import annotations
+
+import os
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[_a] = _b
+
+
+def random_seq(rs: np.random.RandomState, n: int) -> np.ndarray:
+    """n uniform random bases as uint8 ASCII."""
+    return _ACGT[rs.randint(0, 4, size=n).astype(np.uint8)]
+
+
+def revcomp(seq: np.ndarray) -> np.ndarray:
+    return _COMP[seq[::-1]]
+
+
+def mutate(rs: np.random.RandomState, seq: np.ndarray, rate: float) -> np.ndarray:
+    """Substitutions only (the tables model Hamming distance), each to a different base."""
+    out = seq.copy()
+    n = len(seq)
+    hit = np.nonzero(rs.random_sample(n) < rate)[0]
+    if len(hit):
+        code = np.searchsorted(_ACGT, out[hit])  # A C G T are sorted in ASCII
+        code = (code + rs.randint(1, 4, size=len(hit))) & 3
+        out[hit] = _ACGT[code]
+    return out
+
+
+def seq_from_str(s: str) -> np.ndarray:
+    return np.frombuffer(s.encode(), dtype=np.uint8).copy()
+
+
+def write_fasta(path: str, contigs, width: int = 60) -> None:
+    """contigs: list of (name, uint8 array).  Also writes path + '.fai'."""
+    fai = []
+    with open(path, "wb") as f:
+        off = 0
+        for name, seq in contigs:
+            hdr = b">" + name.encode() + b"\n"
+            f.write(hdr)
+            off += len(hdr)
+            n = len(seq)
+            fai.append((name, n, off, width, width + 1))
+            full = n // width
+            if full:
+                body = np.empty((full, width + 1), dtype=np.uint8)
+                body[:, :width] = seq[: full * width].reshape(full, width)
+                body[:, width] = 10
+                f.write(body.tobytes())
+            rest = n - full * width
+            if rest:
+                f.write(seq[full * width:].tobytes() + b"\n")
+            off += n + full + (1 if rest else 0)
+    with open(path + ".fai", "w") as f:
+        for row in fai:
+            f.write("%s\t%d\t%d\t%d\t%d\n" % row)
+
+
+# --------------------------------------------------------------------------
+# split files (what cora.cpp:295-314 hands to homTable_setup as argv[3]/argv[6])
+# --------------------------------------------------------------------------
+def _canonical_mers(k: int):
+    out = []
+    for i in range(4 ** k):
+        s = "".join("ACGT"[(i >> (2 * (k - 1 - j))) & 3] for j in range(k))
+        rc = "".join({"A": "T", "C": "G", "G": "C", "T": "A"}[c] for c in reversed(s))
+        if s <= rc:
+            out.append(s)
+    return out
+
+
+def write_round_robin_splits(path: str, k: int, n: int) -> None:
+    """A valid split file with n groups: canonical k-mers dealt round-robin.
+
+    The reference's tables are invariant to the partition,
+    so any partition that covers every k-mer once is a legal argv[3] (k=2) or
+    argv[6] (k=4).  cora itself uses its LPT_2.dat / LPT_4.dat lines."""
+    mers = _canonical_mers(k)
+    groups = [[] for _ in range(n)]
+    for i, m in enumerate(mers):
+        groups[i % n].append(m)
+    with open(path, "w") as f:
+        f.write("%d\n" % n)
+        for g in groups:
+            f.write(" ".join(g) + "\n")
+
+
+# --------------------------------------------------------------------------
+# workloads
+# --------------------------------------------------------------------------
+def genome_with_families(seed: int, total_len: int, families, n_runs=(), lower=(), name="chrS"):
+    """One contig of uniform random ACGT with repeat families injected.
+
+    families: list of (unit_len, copies, divergence, rc_every) -- each copy is an
+    independently mutated instance of a random unit, every ``rc_every``-th copy
+    reverse-complemented (0 = never), dropped at random non-overlapping slots.
+    n_runs: list of (start, length) stretches overwritten with N.
+    lower: list of (start, length) stretches lower-cased."""
+    rs = np.random.RandomState(seed)
+    g = random_seq(rs, total_len)
+    slot = max(u for u, _, _, _ in families) if families else 1
+    nslots = total_len // slot
+    need = sum(c for _, c, _, _ in families)
+    assert need <= nslots, "families do not fit"
+    slots = rs.permutation(nslots)[:need]
+    si = 0
+    for unit_len, copies, div, rc_every in families:
+        unit = random_seq(rs, unit_len)
+        for c in range(copies):
+            inst = mutate(rs, unit, div)
+            if rc_every and c % rc_every == rc_every - 1:
+                inst = revcomp(inst)
+            at = int(slots[si]) * slot
+            si += 1
+            g[at:at + unit_len] = inst
+    for st, ln in n_runs:
+        g[st:st + ln] = ord("N")
+    for st, ln in lower:
+        seg = g[st:st + ln]
+        g[st:st + ln] = np.where(seg != ord("N"), seg | 0x20, seg)
+    return [(name, g)]
+
+
+def workload_ecoli_like(seed: int = 2024):
+    """configs[0]: 4.6 Mbp, 5 families x 12 copies x 1.2 kbp at 1 % divergence."""
+    return genome_with_families(seed, 4_600_000, [(1200, 12, 0.01, 3)] * 5, name="ecoli_like")
+
+
+def workload_chr20_like(seed: int = 20, total_len: int = 64_000_000):
+    """configs[1]: chr20-sized contig, 0.5 Mbp leading N-run, repeat families
+    totalling about 5 % of the length at 2 % divergence."""
+    scale = total_len / 64_000_000
+    fams = []
+    rs = np.random.RandomState(seed + 1)
+    budget = int(0.05 * total_len)
+    while budget > 0:
+        unit = int(rs.choice([300, 600, 1200, 2400, 6000]))
+        copies = int(rs.randint(4, 21))
+        if unit * copies > budget:
+            copies = max(2, budget // unit)
+        fams.append((unit, copies, 0.02, 3))
+        budget -= unit * copies
+    nlead = int(500_000 * scale)
+    return genome_with_families(seed, total_len, fams, n_runs=[(0, nlead)], name="chr20_like")
+
+
+def ensure_dir(p: str) -> str:
+    os.makedirs(p, exist_ok=True)
+    return p

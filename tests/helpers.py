@@ -1,0 +1,98 @@
+"""Shared test plumbing: golden manifest, input materialisation, oracle runner."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_BIN = os.path.join(ORACLE_DIR, "hts_oracle")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref", "homTable_setup")
+
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+_cache_dir = None
+
+
+def scratch():
+    global _cache_dir
+    if _cache_dir is None:
+        _cache_dir = tempfile.mkdtemp(prefix="cora_tests_")
+    return _cache_dir
+
+
+def sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def input_path(name):
+    """FASTA of a golden input; recipe-only inputs are rebuilt and sha256-checked."""
+    meta = MANIFEST["inputs"][name]
+    if not meta["recipe_only"]:
+        return os.path.join(GOLDEN, "inputs", name + ".fa")
+    p = os.path.join(scratch(), name + ".fa")
+    if not os.path.exists(p):
+        sys.path.insert(0, GOLDEN)
+        import make_golden
+        from cora_amd import synth
+        synth.write_fasta(p, make_golden.INPUTS[name](), 60)
+        assert sha256(p) == meta["sha256"], "recipe for %s no longer reproduces the pinned input" % name
+    return p
+
+
+def split_path(kind, n):
+    return os.path.join(GOLDEN, "splits", "%s_%d.txt" % (kind, n))
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_BIN) or os.path.getmtime(ORACLE_BIN) < os.path.getmtime(os.path.join(ORACLE_DIR, "hts_oracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "hts_oracle", "liboracle_sort.so"], stdout=subprocess.DEVNULL)
+    return ORACLE_BIN
+
+
+def run_tool(binary, fasta, K, d, phys, par, outdir, L=False, extra=()):
+    """Runs a homTable_setup-compatible executable; returns (exact_path, inexact_path, proc)."""
+    os.makedirs(outdir, exist_ok=True)
+    ex, inx = os.path.join(outdir, "Exact"), os.path.join(outdir, "Inexact")
+    for p in (ex, inx, ex + ".itemCount", inx + ".itemCount"):
+        if os.path.exists(p):
+            os.remove(p)
+    cmd = [binary, fasta, str(K), phys, ex, inx, par, "BOTH", str(d), "FULL"] + list(extra)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return ex, inx, r
+
+
+def run_oracle(fasta, K, d, phys, par, outdir, L=False):
+    ex, inx, r = run_tool(build_oracle(), fasta, K, d, phys, par, outdir, extra=(["L"] if L else []))
+    assert r.returncode == 0, r.stdout[-2000:]
+    return ex, inx
+
+
+def read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def golden_case(name):
+    c = MANIFEST["cases"][name]
+    d = os.path.join(GOLDEN, "cases", name)
+    return c, d
+
+
+def assert_same_tables(got_ex, got_inx, want_dir, label=""):
+    for got, fn in ((got_ex, "Exact"), (got_inx, "Inexact")):
+        w = read(os.path.join(want_dir, fn))
+        g = read(got)
+        if g != w:
+            n = min(len(g), len(w))
+            first = next((i for i in range(n) if g[i] != w[i]), n)
+            raise AssertionError("%s %s differs: got %d B, want %d B, first difference at byte %d" % (label, fn, len(g), len(w), first))
+        wc = read(os.path.join(want_dir, fn + ".itemCount"))
+        gc = read(got + ".itemCount")
+        assert gc == wc, "%s %s.itemCount: got %r want %r" % (label, fn, gc, wc)
