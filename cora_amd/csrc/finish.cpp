@@ -1,0 +1,264 @@
+// finish.cpp -- host side of the table build (see finish.hpp).
+// HTS = /root/reference/homTable_setup.cpp.
+#include "finish.hpp"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <string.h>
+#include <tuple>
+
+namespace cora {
+
+uint32_t HostGenome::contig_of(uint64_t g) const
+{
+    // gstart has n_contigs+1 entries; the last one is G
+    auto it = std::upper_bound(gstart.begin(), gstart.end() - 1, g);
+    return (uint32_t)(it - gstart.begin()) - 1;
+}
+
+// HTS:2015-2066.  n = d+1 seeds; long read-mers: positions i < 8n carry seed 1 + i mod n and are
+// mirrored at K-1-i; short ones: q = K/(2n) bases per half, the remainder in the middle unassigned.
+void make_seed_template(int K, int d, char *tmpl, int *seed_q)
+{
+    const int n = d + 1;
+    memset(tmpl, 0, (size_t)K);
+    int span;
+    if (K >= 16 * n) { span = 8 * n; *seed_q = 8; }
+    else { span = K / 2 - (K % (2 * n)) / 2; *seed_q = K / (2 * n); }
+    for (int i = 0; i < span; i++) { tmpl[i] = (char)(1 + i % n); tmpl[K - 1 - i] = (char)(1 + i % n); }
+}
+
+// HTS:2069-2116: first three positions of the seed from the left (so, ts1, ts2) and from the right
+// (eo, te1, te2).
+void seed_signal_offsets(int K, const char *tmpl, int seed, int off[6])
+{
+    int left[3] = {-1, -1, -1}, right[3] = {-1, -1, -1}, nl = 0, nr = 0;
+    for (int i = 0; i < K && nl < 3; i++) if (tmpl[i] == seed) left[nl++] = i;
+    for (int i = K - 1; i > left[2] && nr < 3; i--) if (tmpl[i] == seed) right[nr++] = i;
+    off[0] = left[0]; off[1] = right[0]; off[2] = left[1]; off[3] = right[1]; off[4] = left[2]; off[5] = right[2];
+}
+
+// HTS:727-765 builds "split runs" of whole contigs (about total/(min(nchr,250)+2) bases each, the last
+// contig never opens a run of its own); HTS:1467-1474 then tests only the LAST contig of a run
+// against the 50 Mbp limit ('=' where '+=' was meant); if it is longer, every contig of the run that
+// is longer than the limit is compacted window by window (HTS:1479,1528-1581).  d == 3 only (HTS:2852-2856).
+void plan_windows(int d, const std::vector<uint32_t> &len, std::vector<uint32_t> &window)
+{
+    const int nchr = (int)len.size();
+    window.assign(nchr, 0);
+    if (d != 3 || nchr == 0) return;
+    const uint32_t limit = 50000000u;
+    int nruns = std::min(nchr, 250) + 2;
+    std::vector<int> run_end(1, 0);                       // 1-based contig ids; run r covers (run_end[r], run_end[r+1]]
+    long long total = 0;
+    for (uint32_t l : len) total += l;
+    const long long aimed = total / nruns;
+    long long sofar = 0;
+    for (int c = 1; c < nchr; c++) {                      // the loop stops at the last contig without adding it
+        sofar += len[c - 1];
+        if (sofar >= aimed) { run_end.push_back(c); sofar = 0; }
+    }
+    run_end.push_back(nchr);
+    for (size_t r = 0; r + 1 < run_end.size(); r++) {
+        const int a = run_end[r] + 1, b = run_end[r + 1];
+        if (b < a) continue;
+        if (len[b - 1] > limit)
+            for (int c = a; c <= b; c++) if (len[c - 1] > limit) window[c - 1] = limit;
+    }
+}
+
+namespace {
+
+struct Writer {
+    std::vector<uint8_t> &v;
+    int cw;                                               // contig id width: 1 or 2 bytes (HTS:210-214)
+    void u8(uint32_t x) { v.push_back((uint8_t)x); }
+    void chr(uint32_t c) { v.push_back((uint8_t)c); if (cw == 2) v.push_back((uint8_t)(c >> 8)); }
+    void u32(uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i))); }
+    void i16(int x) { v.push_back((uint8_t)x); v.push_back((uint8_t)((unsigned)x >> 8)); }
+};
+
+}  // namespace
+
+// F1 (HTS:572-635): rep chr,pos  { dir chr pos }*  0xFF  blockSize; only a block's first class is written.
+void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, std::vector<uint8_t> &out, FinishStats &st)
+{
+    out.clear();
+    Writer w{out, g.chr_short ? 2 : 1};
+    const size_t n = r.cls.size();
+    st.exact_nodes = 0;
+    for (size_t c = 0; c < n;) {
+        size_t e = c + 1;
+        while (e < n && r.merge_prev[e]) e++;
+        const uint64_t o = r.ent_off[c];
+        const uint32_t ne = r.cls_entries[c];
+        for (uint32_t k = 0; k < ne; k++) {
+            const uint32_t gp = r.ent[o + k];
+            const uint32_t ci = g.contig_of(gp);
+            if (k) w.u8(r.ent_dir[o + k]);
+            w.chr(ci + 1);
+            w.u32((uint32_t)(gp - g.gstart[ci]) + 1);
+        }
+        w.u8(0xFF);
+        w.u32((uint32_t)(e - c));
+        st.exact_nodes++;
+        c = e;
+    }
+}
+
+namespace {
+
+struct DItem {                                            // one directed item in a list that needs the exact order
+    uint32_t tgt;
+    uint8_t dir, o1, o2, o3;
+    int16_t blen;
+    std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> ord;
+};
+
+inline uint32_t base_of(const std::vector<uint64_t> &pk, uint64_t gp)
+{
+    return (uint32_t)(pk[gp >> 5] >> (62 - 2 * (gp & 31))) & 3u;
+}
+
+// HTS:1159-1191: one candidate only -- walk forward from the cursor to the first target >= wanted,
+// back to the last target <= wanted, then test that single item.
+int search_one(const std::vector<DItem> &v, int last, uint32_t tgt, int dir, int o1, int o2, int o3)
+{
+    const int n = (int)v.size();
+    int cur = last;
+    while (cur < n && v[cur].tgt < tgt) cur++;
+    if (cur >= n) cur = n - 1;
+    while (cur >= 0 && v[cur].tgt > tgt) cur--;
+    if (cur < 0) cur = 0;
+    const DItem &x = v[cur];
+    if (x.tgt != tgt || x.dir != dir || x.o1 != o1 || x.o2 != o2 || x.o3 != o3) return -1;
+    return cur;
+}
+
+void emit_item(Writer &w, const HostGenome &g, int d, uint32_t tgt, uint32_t dir, uint32_t o1, uint32_t o2, uint32_t o3, int blen)
+{
+    const uint32_t ci = g.contig_of(tgt);
+    w.u8(dir);
+    w.chr(ci + 1);
+    w.u32((uint32_t)(tgt - g.gstart[ci]) + 1);
+    w.u8(o1);
+    if (d > 1) w.u8(o2);
+    if (d > 2) w.u8(o3);
+    w.i16(blen);
+}
+
+}  // namespace
+
+// F2 (HTS:1353-1432): per source position with a surviving item: chr,pos { dir chr pos off.. blockLen }* 0xFF,
+// items by decreasing block length through std::sort (HTS:1368; unstable above 16 items, which is why the
+// very same library routine is applied to the very same pre-order here).
+void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, const std::vector<uint64_t> &packed,
+                       std::vector<uint8_t> &out, FinishStats &st)
+{
+    out.clear();
+    Writer w{out, g.chr_short ? 2 : 1};
+    st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
+    const size_t n_nodes = r.node_start.empty() ? 0 : r.node_start.size() - 1;
+    auto src_of = [&](size_t nd) { return (uint32_t)(r.key[r.node_start[nd]] >> 32); };
+    auto same_win = [&](uint32_t a, uint32_t b, uint32_t ci) {
+        const uint32_t wl = g.window[ci];
+        if (!wl) return true;
+        return (a - g.gstart[ci]) / wl == (b - g.gstart[ci]) / wl;
+    };
+    int sig_off[4][6];
+    for (int s = 1; s <= g.d + 1; s++) seed_signal_offsets(g.K, g.tmpl, s, sig_off[s - 1]);
+
+    std::vector<std::pair<int16_t, uint32_t>> order;
+    size_t i = 0;
+    while (i < n_nodes) {
+        // maximal run of consecutive source positions inside one compaction window
+        const uint32_t s0 = src_of(i);
+        const uint32_t ci = g.contig_of(s0);
+        size_t j = i + 1;
+        while (j < n_nodes && src_of(j) == src_of(j - 1) + 1 && same_win(src_of(j - 1), src_of(j), ci)) j++;
+        bool dirty = false;
+        for (size_t nd = i; nd < j && !dirty; nd++)
+            for (uint32_t k = r.node_start[nd] + 1; k < r.node_start[nd + 1]; k++)
+                if (r.key[k] == r.key[k - 1]) { dirty = true; break; }
+        if (!dirty) {
+            for (size_t nd = i; nd < j; nd++) {
+                const uint32_t a = r.node_start[nd], b = r.node_start[nd + 1];
+                order.clear();
+                for (uint32_t k = a; k < b; k++) order.emplace_back(r.blen[k], k);
+                if (b - a > 16) st.big_nodes++;
+                std::sort(order.begin(), order.end(),
+                          [](const std::pair<int16_t, uint32_t> &x, const std::pair<int16_t, uint32_t> &y) { return x.first > y.first; });
+                bool header = false;
+                for (auto &e : order) {
+                    if (e.first == -1) continue;
+                    if (!header) { const uint32_t sp = src_of(nd); w.chr(ci + 1); w.u32((uint32_t)(sp - g.gstart[ci]) + 1); header = true; }
+                    const uint32_t m = r.meta[e.second];
+                    emit_item(w, g, g.d, (uint32_t)r.key[e.second], m & 1u, meta_o1(m), meta_o2(m), meta_o3(m), e.first);
+                }
+                if (header) { w.u8(0xFF); st.inexact_nodes++; }
+            }
+            i = j;
+            continue;
+        }
+        // ---- a list of the run has tied targets: redo the run in the reference's own order ----
+        std::vector<std::vector<DItem>> L(j - i);
+        for (size_t nd = i; nd < j; nd++) {
+            std::vector<DItem> &lst = L[nd - i];
+            const uint32_t a = r.node_start[nd], b = r.node_start[nd + 1];
+            bool tie = false;
+            for (uint32_t k = a; k < b; k++) {
+                const uint32_t src = (uint32_t)(r.key[k] >> 32), tgt = (uint32_t)r.key[k], m = r.meta[k];
+                if (k > a && r.key[k] == r.key[k - 1]) tie = true;
+                DItem it;
+                it.tgt = tgt; it.dir = (uint8_t)(m & 1u); it.o1 = (uint8_t)meta_o1(m); it.o2 = (uint8_t)meta_o2(m); it.o3 = (uint8_t)meta_o3(m);
+                it.blen = 1;
+                // position of the pair record in the reference's pair files (HTS:2671-2800) and of this
+                // item among the pushes (HTS:1591-1619): file t, group g, seed s, scan position of k-mer 1,
+                // pass (normal / palindrome), chain walk = later insertions first, duplicate, push side.
+                const uint32_t p1 = std::max(src, tgt), p2 = std::min(src, tgt);
+                const int *so = sig_off[meta_seed0(m)];
+                const uint32_t grp = g.sig2[base_of(packed, (uint64_t)p1 + so[0]) * 4 + base_of(packed, (uint64_t)p1 + so[1])];
+                const uint32_t thr = g.sig4[base_of(packed, (uint64_t)p1 + so[2]) * 64 + base_of(packed, (uint64_t)p1 + so[4]) * 16 +
+                                            base_of(packed, (uint64_t)p1 + so[5]) * 4 + base_of(packed, (uint64_t)p1 + so[3])];
+                const uint32_t side = (src == p1) ? 0u : 1u;
+                it.ord = std::make_tuple(thr, grp, meta_seed0(m), p1, meta_pass(m), ~p2, meta_dup(m) * 2 + side);
+                lst.push_back(it);
+            }
+            if (tie) st.dirty_nodes++;
+            if (b - a > 16) st.big_nodes++;
+            std::sort(lst.begin(), lst.end(), [](const DItem &x, const DItem &y) { return x.ord < y.ord; });      // push order
+            std::sort(lst.begin(), lst.end(), [](const DItem &x, const DItem &y) { return x.tgt < y.tgt; });      // HTS:1141
+        }
+        const size_t nl = L.size();
+        for (size_t k = 0; k < nl; k++) {
+            std::vector<DItem> &base = L[k];
+            for (size_t dist = 1; k + dist < nl; dist++) {                                                        // HTS:1203-1270
+                std::vector<DItem> &comp = L[k + dist];
+                int last = 0;
+                for (DItem &b : base) {
+                    if (b.blen != (int)dist) continue;
+                    const uint32_t tc = g.contig_of(b.tgt);
+                    const long long pos1 = (long long)(b.tgt - g.gstart[tc]) + 1;
+                    const long long want = b.dir == 0 ? pos1 + (long long)dist : pos1 - (long long)dist;
+                    if (want <= 0 || want > (long long)g.len[tc]) continue;
+                    const int o1 = (int)b.o1 - (int)dist, o2 = b.o2 ? (int)b.o2 - (int)dist : 0, o3 = b.o3 ? (int)b.o3 - (int)dist : 0;
+                    if (o1 <= 0 || o2 < 0 || o3 < 0) continue;
+                    const uint32_t want_g = b.dir == 0 ? b.tgt + (uint32_t)dist : b.tgt - (uint32_t)dist;
+                    const int at = search_one(comp, last, want_g, b.dir, o1, o2, o3);
+                    if (at != -1) { last = at; b.blen++; comp[at].blen = -1; }
+                }
+            }
+            std::sort(base.begin(), base.end(), [](const DItem &x, const DItem &y) { return x.blen > y.blen; });  // HTS:1368
+            bool header = false;
+            for (const DItem &b : base) {
+                if (b.blen == -1) continue;
+                if (!header) { const uint32_t sp = s0 + (uint32_t)k; w.chr(ci + 1); w.u32((uint32_t)(sp - g.gstart[ci]) + 1); header = true; }
+                emit_item(w, g, g.d, b.tgt, b.dir, b.o1, b.o2, b.o3, b.blen);
+            }
+            if (header) { w.u8(0xFF); st.inexact_nodes++; }
+        }
+        i = j;
+    }
+}
+
+}  // namespace cora

@@ -1,0 +1,54 @@
+// finish.hpp -- host side of the table build: turns the structured device results into the
+// reference's byte streams (F1 <Exact>, F2 <Inexact>), applies libstdc++ std::sort where the
+// reference does, and redoes lists with tied targets in the reference's discovery order.
+// HTS = /root/reference/homTable_setup.cpp.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace cora {
+
+struct HostGenome {
+    int K = 0, d = 0, chr_short = 0;
+    int n_groups = 0, n_threads = 0;
+    uint8_t sig2[16];
+    uint8_t sig4[256];
+    std::vector<uint64_t> gstart;      // [n_contigs+1], last = G
+    std::vector<uint32_t> len;         // [n_contigs]
+    std::vector<uint32_t> window;      // [n_contigs] 0 or 50,000,000 (d == 3 sub-contig compaction)
+    char tmpl[72];                     // seed template, 0 = unassigned (HTS:2015-2066)
+    int seed_q = 8;
+    // contig index (0-based) holding global position g
+    uint32_t contig_of(uint64_t g) const;
+};
+
+// Seed template and per-seed signal offsets (HTS:2015-2116), shared by the host set-up.
+void make_seed_template(int K, int d, char *tmpl /*[K]*/, int *seed_q);
+void seed_signal_offsets(int K, const char *tmpl, int seed, int off[6] /* so, eo, ts1, te1, ts2, te2 */);
+// Which contigs the reference compacts in 50 Mbp windows (HTS:727-765, 1467-1479, 2845-2860).
+void plan_windows(int d, const std::vector<uint32_t> &len, std::vector<uint32_t> &window);
+
+struct ExactDeviceResult {             // classes with >= 2 entries, sorted by representative
+    std::vector<uint64_t> cls;         // rep<<32 | start (start unused on the host)
+    std::vector<uint32_t> cls_entries; // entries per class (representative included)
+    std::vector<uint64_t> ent_off;     // first entry of each class
+    std::vector<uint32_t> ent;         // entry positions (global coordinate)
+    std::vector<uint8_t> ent_dir;      // entry directions
+    std::vector<uint8_t> merge_prev;   // class continues the block of the previous class
+};
+
+struct InexactDeviceResult {           // directed items sorted by (source, target)
+    std::vector<uint64_t> key;         // src<<32 | tgt
+    std::vector<uint32_t> meta;        // kernels.hpp bit layout
+    std::vector<int16_t> blen;         // -1 absorbed, else block length (valid for lists without ties)
+    std::vector<uint32_t> node_start;  // [n_nodes+1]
+};
+
+struct FinishStats { uint64_t exact_nodes = 0, inexact_nodes = 0, dirty_nodes = 0, big_nodes = 0; };
+
+void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, std::vector<uint8_t> &out, FinishStats &st);
+// packed: the 2-bit genome (needed only when a list has tied targets); may be empty if none has.
+void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, const std::vector<uint64_t> &packed,
+                       std::vector<uint8_t> &out, FinishStats &st);
+
+}  // namespace cora

@@ -1,0 +1,674 @@
+// kernels.hip -- the homology-table pipeline on gfx950: 2-bit pack straight from the FASTA
+// file image, canonical K-mer keys, class/representative detection over the sorted keys,
+// pigeonhole seed codes, equal-run pair verification by XOR + popcount on the packed genome,
+// directed items and diagonal block merging.  Integer work only; HBM / L2 bound.
+// HTS = /root/reference/homTable_setup.cpp (cited per kernel for the behaviour restated).
+#include "kernels.hpp"
+
+namespace cora {
+
+constexpr u64 M55 = 0x5555555555555555ull;
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ u32 find_contig(const DevParams &p, u64 g)
+{
+    // largest c with ctg_gstart[c] <= g   (ctg_gstart[n_contigs] = G)
+    u32 lo = 0, hi = p.n_contigs;
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (p.ctg_gstart[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void load_window(const DevParams &p, const u64 *__restrict__ pk, u64 g, u64 &hi, u64 &lo)
+{
+    const u64 w = g >> 5;
+    const int sh = (int)(g & 31) * 2;
+    const u64 x0 = pk[w], x1 = pk[w + 1], x2 = pk[w + 2];
+    if (sh) { hi = (x0 << sh) | (x1 >> (64 - sh)); lo = (x1 << sh) | (x2 >> (64 - sh)); }
+    else { hi = x0; lo = x1; }
+    lo &= p.kmask_lo;
+}
+
+__device__ __forceinline__ u64 rev2(u64 x)
+{
+    x = __brevll(x);
+    return ((x >> 1) & M55) | ((x & M55) << 1);
+}
+
+// reverse complement of a left-aligned K-mer (HTS:1941-1951 restated on two words)
+__device__ __forceinline__ void rc_window(int K, u64 hi, u64 lo, u64 &rhi, u64 &rlo)
+{
+    const u64 H = ~rev2(lo), L = ~rev2(hi);
+    const int s = 2 * (64 - K);
+    if (s) { rhi = (H << s) | (L >> (64 - s)); rlo = L << s; }
+    else { rhi = H; rlo = L; }
+}
+
+__device__ __forceinline__ u32 base_at(u64 hi, u64 lo, int i)
+{
+    return (u32)((i < 32 ? hi >> (62 - 2 * i) : lo >> (62 - 2 * (i - 32))) & 3u);
+}
+
+__device__ __forceinline__ bool bad_bit(const u32 *__restrict__ bad, u64 g)
+{
+    return (bad[g >> 5] >> (31 - (u32)(g & 31))) & 1u;
+}
+
+// Is there a K-mer window at g that the reference's scan would visit?
+// N-free window (HTS:2619-2636) minus the Q4 case: GetFirstNonNreadmer (HTS:1954-1981)
+// never *finds* a window ending on the contig's last base, so a final N-free stretch of
+// exactly K bases yields no window.
+__device__ __forceinline__ bool window_ok(const DevParams &p, const u32 *__restrict__ bad, u64 g)
+{
+    if (g + (u64)p.K > p.G) return false;
+    const u64 w = g >> 5;
+    const int o = (int)(g & 31);
+    u64 x = ((u64)bad[w] << 32) | bad[w + 1];
+    if (o) x = (x << o) | (u64)(bad[w + 2] >> (32 - o));
+    if (x >> (64 - p.K)) return false;
+    if (bad_bit(bad, g + p.K)) {
+        const u32 c = find_contig(p, g);
+        if (g + p.K == p.ctg_gstart[c] + p.ctg_len[c]) {
+            if (g == p.ctg_gstart[c]) return false;
+            if (bad_bit(bad, g - 1)) return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32 *lds4, u32 *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds4[wv] = x;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { u32 s = lds4[w]; if (w < wv) base += s; tot += s; }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+// ------------------------------------------------------------------ pack
+// One thread packs 32 bases of the global coordinate into one u64 (base i at bits 62-2i)
+// and one validity word.  Bases are read from the FASTA image: base `local` of a contig
+// sits at ctg_off + local + local / line_width (HTS:96-142: fixed line width, '\n' ends).
+// Upper-casing and "everything but ACGT is N" follow HTS:131-136.
+__global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict__ raw, u64 *__restrict__ pk,
+                                              u32 *__restrict__ bad, DevCounters *ctr)
+{
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= p.n_words + 4) return;
+    u64 packed = 0;
+    u32 badw = 0xFFFFFFFFu;
+    if (w < p.n_words) {
+        const u64 g0 = w << 5;
+        const u32 c = find_contig(p, g0);
+        const u64 local0 = g0 - p.ctg_gstart[c];
+        const u32 len = p.ctg_len[c];
+        if (local0 < len) {
+            const u64 off0 = p.ctg_off[c];
+            u64 line = local0 / p.line_width;
+            u32 col = (u32)(local0 - line * p.line_width);
+            u32 errs = 0;
+            badw = 0;
+#pragma unroll 4
+            for (int i = 0; i < 32; i++) {
+                const u64 local = local0 + i;
+                u32 code = 0, isbad = 1;
+                if (local < len) {
+                    const u64 at = off0 + local + line;
+                    u32 ch = (at < p.image_bytes) ? raw[at] : (u32)'\n';
+                    if (ch == '\n' || ch == '>') errs++;
+                    if (ch > 'Z') ch -= 32;
+                    isbad = 0;
+                    if (ch == 'A') code = 0; else if (ch == 'C') code = 1; else if (ch == 'G') code = 2; else if (ch == 'T') code = 3;
+                    else isbad = 1;
+                    if (col + 1 == p.line_width || local + 1 == len) {      // a line must end here
+                        const u64 nl = at + 1;
+                        if (nl < p.image_bytes && raw[nl] != '\n') errs++;
+                    }
+                    if (++col == p.line_width) { col = 0; line++; }
+                }
+                packed |= (u64)code << (62 - 2 * i);
+                badw |= isbad << (31 - i);
+            }
+            if (errs) atomicAdd(&ctr->format_errors, (unsigned long long)errs);
+        }
+    }
+    pk[w] = packed;
+    bad[w] = badw;
+}
+
+// ------------------------------------------------------------------ valid windows -> keys
+__global__ __launch_bounds__(256) void k_kmer_count(DevParams p, const u32 *__restrict__ bad, u32 *__restrict__ block_counts)
+{
+    __shared__ u32 wsum[4];
+    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = (g < p.G) && window_ok(p, bad, g);
+    const u64 bal = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// canonical key = lexicographically smaller of forward / reverse complement (HTS:2551-2565)
+__global__ __launch_bounds__(256) void k_kmer_emit(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ bad,
+                                                   const u64 *__restrict__ block_off, u64 *__restrict__ key_hi,
+                                                   u64 *__restrict__ key_lo, u32 *__restrict__ gpos)
+{
+    __shared__ u32 wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = (g < p.G) && window_ok(p, bad, g);
+    const u64 bal = __ballot(ok);
+    if (lane == 0) wsum[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    if (!ok) return;
+    u32 pre = 0;
+    for (int w = 0; w < wv; w++) pre += wsum[w];
+    const u64 at = block_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+    u64 hi, lo, rhi, rlo;
+    load_window(p, pk, g, hi, lo);
+    rc_window(p.K, hi, lo, rhi, rlo);
+    const bool use_rc = (rhi < hi) || (rhi == hi && rlo < lo);
+    key_hi[at] = use_rc ? rhi : hi;
+    key_lo[at] = use_rc ? rlo : lo;
+    gpos[at] = (u32)g;
+}
+
+// a contig without any window makes the reference read before its buffer (HTS:2530): count them
+__global__ __launch_bounds__(256) void k_contig_check(DevParams p, const u32 *__restrict__ gpos, u64 n, DevCounters *ctr)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.n_contigs) return;
+    const u64 lo_g = p.ctg_gstart[c], hi_g = lo_g + p.ctg_len[c];
+    u64 a = 0, b = n;
+    while (a < b) {
+        const u64 mid = (a + b) >> 1;
+        if (gpos[mid] < lo_g) a = mid + 1; else b = mid;
+    }
+    if (a >= n || gpos[a] >= hi_g) atomicAdd(&ctr->empty_contigs, 1ull);
+}
+
+// ------------------------------------------------------------------ classes over the sorted keys
+__device__ __forceinline__ u32 window_group(const DevParams &p, const u64 *__restrict__ pk, u64 g)
+{
+    u64 hi, lo;
+    load_window(p, pk, g, hi, lo);
+    return p.sig2[base_at(hi, lo, 0) * 4 + base_at(hi, lo, p.K - 1)];     // HTS:2549
+}
+
+__device__ __forceinline__ bool key_is_palindrome(int K, u64 hi, u64 lo)
+{
+    if (K & 1) return false;
+    u64 rhi, rlo;
+    rc_window(K, hi, lo, rhi, rlo);
+    return rhi == hi && rlo == lo;
+}
+
+// Counts representatives (= classes, HTS:2573-2578), classes with >= 2 entries, and finds the
+// first singleton class in the reference's class-id order (group, position): classes created
+// before it escape the direction flip (Q3, HTS:421-433).
+__global__ __launch_bounds__(256) void k_class_count(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ hi,
+                                                     const u64 *__restrict__ lo, const u32 *__restrict__ gpos, u64 n,
+                                                     DevCounters *ctr)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool head = false, nons = false;
+    if (i < n) {
+        const u64 h = hi[i], l = lo[i];
+        head = (i == 0) || hi[i - 1] != h || lo[i - 1] != l;
+        if (head) {
+            const bool next_head = (i + 1 == n) || hi[i + 1] != h || lo[i + 1] != l;
+            if (next_head && !key_is_palindrome(p.K, h, l)) {
+                const u64 g = gpos[i];
+                const unsigned long long key = ((unsigned long long)window_group(p, pk, g) << 32) | g;
+                atomicMin(&ctr->first_singleton_key, key);
+            } else nons = true;
+        }
+    }
+    const u64 bh = __ballot(head), bn = __ballot(nons);
+    if ((threadIdx.x & 63) == 0) {
+        if (bh) atomicAdd(&ctr->n_reps, (unsigned long long)__popcll(bh));
+        if (bn) atomicAdd(&ctr->n_nonsingle, (unsigned long long)__popcll(bn));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_class_emit(DevParams p, const u64 *__restrict__ hi, const u64 *__restrict__ lo,
+                                                    const u32 *__restrict__ gpos, u64 n, u32 *__restrict__ repmask,
+                                                    u64 *__restrict__ cls, u32 *__restrict__ cls_fill)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 h = hi[i], l = lo[i];
+    const bool head = (i == 0) || hi[i - 1] != h || lo[i - 1] != l;
+    if (!head) return;
+    const u32 g = gpos[i];
+    atomicOr(&repmask[g >> 5], 1u << (31 - (g & 31)));
+    const bool next_head = (i + 1 == n) || hi[i + 1] != h || lo[i + 1] != l;
+    if (!(next_head && !key_is_palindrome(p.K, h, l))) {
+        const u32 at = atomicAdd(cls_fill, 1u);
+        cls[at] = ((u64)g << 32) | (u64)(u32)i;
+    }
+}
+
+// ------------------------------------------------------------------ bitmap -> sorted position list
+__global__ __launch_bounds__(256) void k_bitmap_count(const u32 *__restrict__ bits, u64 n_words, u32 *__restrict__ block_counts)
+{
+    __shared__ u32 l4[4];
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u32 c = (w < n_words) ? (u32)__popc(bits[w]) : 0u;
+    u32 tot;
+    (void)block_excl_scan_u32(c, l4, &tot);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_bitmap_emit(const u32 *__restrict__ bits, u64 n_words, const u64 *__restrict__ block_off,
+                                                     u32 *__restrict__ out)
+{
+    __shared__ u32 l4[4];
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 word = (w < n_words) ? bits[w] : 0u;
+    u64 at = block_off[blockIdx.x] + block_excl_scan_u32((u32)__popc(word), l4, nullptr);
+    while (word) {
+        const int lz = __clz((int)word);
+        out[at++] = (u32)(w * 32 + lz);
+        word &= ~(0x80000000u >> lz);
+    }
+}
+
+// ------------------------------------------------------------------ exact table pieces
+// cls[c] = rep<<32 | start, sorted by rep.  flags: bit0 palindrome, bit1 flip, bit2 rep strand, bit3 leading.
+__global__ __launch_bounds__(256) void k_class_info(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ hi,
+                                                    const u64 *__restrict__ lo, u64 n, const u64 *__restrict__ cls, u32 n_cls,
+                                                    const DevCounters *__restrict__ ctr, u32 *__restrict__ cls_m,
+                                                    u32 *__restrict__ cls_flags, u32 *__restrict__ cls_entries)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cls) return;
+    const u64 rep = cls[c] >> 32, start = cls[c] & 0xFFFFFFFFull;
+    const u64 h = hi[start], l = lo[start];
+    u64 a = start + 1, b = n;
+    while (a < b) {
+        const u64 mid = (a + b) >> 1;
+        if (hi[mid] == h && lo[mid] == l) a = mid + 1; else b = mid;
+    }
+    const u32 m = (u32)(a - start);
+    const bool pal = key_is_palindrome(p.K, h, l);
+    u64 fh, fl;
+    load_window(p, pk, rep, fh, fl);
+    const bool strand = !(fh == h && fl == l);                 // canonical form is the reverse complement
+    const unsigned long long ord = ((unsigned long long)p.sig2[base_at(fh, fl, 0) * 4 + base_at(fh, fl, p.K - 1)] << 32) | rep;
+    const bool leading = ord < ctr->first_singleton_key;      // class id precedes the first singleton's (Q3)
+    const bool flip = strand && !leading;
+    cls_m[c] = m;
+    cls_flags[c] = (pal ? 1u : 0u) | (flip ? 2u : 0u) | (strand ? 4u : 0u) | (leading ? 8u : 0u);
+    cls_entries[c] = m * (pal ? 2u : 1u);
+}
+
+// entries of a class in the reference's list order (HTS:356-408): occurrences by position;
+// dir = strandSwitched (HTS:2552-2565), flipped when the representative's is 1 (HTS:424-432);
+// a palindromic K-mer contributes (0,pos),(1,pos) (Q2, HTS:2597-2616).
+__global__ __launch_bounds__(256) void k_class_entries(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ gpos,
+                                                       const u64 *__restrict__ cls, u32 n_cls, const u32 *__restrict__ cls_m,
+                                                       const u32 *__restrict__ cls_flags, const u64 *__restrict__ ent_off,
+                                                       u32 *__restrict__ ent, u8 *__restrict__ ent_dir)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cls) return;
+    const u64 start = cls[c] & 0xFFFFFFFFull;
+    const u32 m = cls_m[c], fl = cls_flags[c];
+    u64 o = ent_off[c];
+    for (u32 j = 0; j < m; j++) {
+        const u32 g = gpos[start + j];
+        if (fl & 1u) {
+            ent[o] = g; ent_dir[o] = 0; ent[o + 1] = g; ent_dir[o + 1] = 1; o += 2;
+        } else {
+            u64 hi, lo, rhi, rlo;
+            load_window(p, pk, g, hi, lo);
+            rc_window(p.K, hi, lo, rhi, rlo);
+            const u32 strand = ((rhi < hi) || (rhi == hi && rlo < lo)) ? 1u : 0u;
+            ent[o] = g; ent_dir[o] = (u8)(strand ^ ((fl >> 1) & 1u)); o++;
+        }
+    }
+}
+
+// Can class c be merged into the block of class c-1?  (HTS:455-497: same size, representative
+// one base further, every other entry same direction and one base further along its strand.)
+__global__ __launch_bounds__(256) void k_class_merge(const u64 *__restrict__ cls, u32 n_cls, const u32 *__restrict__ cls_entries,
+                                                     const u64 *__restrict__ ent_off, const u32 *__restrict__ ent,
+                                                     const u8 *__restrict__ ent_dir, u8 *__restrict__ merge_prev)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cls) return;
+    u8 ok = 0;
+    if (c > 0 && (cls[c] >> 32) == (cls[c - 1] >> 32) + 1 && cls_entries[c] == cls_entries[c - 1]) {
+        const u64 oa = ent_off[c - 1], ob = ent_off[c];
+        const u32 ne = cls_entries[c];
+        ok = 1;
+        for (u32 k = 1; k < ne; k++) {
+            const u8 da = ent_dir[oa + k];
+            if (da != ent_dir[ob + k]) { ok = 0; break; }
+            const u32 want = da ? ent[oa + k] - 1u : ent[oa + k] + 1u;
+            if (ent[ob + k] != want) { ok = 0; break; }
+        }
+    }
+    merge_prev[c] = ok;
+}
+
+// ------------------------------------------------------------------ seeds
+// 32-bit seed code (HTS:1793-1838): the seed's left positions s-1, s-1+n, ... ascending, then
+// (8-q) literal A,T pairs, then its mirrored right positions ascending.
+__device__ __forceinline__ u32 seed_code(const DevParams &p, u64 hi, u64 lo, int seed /*1-based*/)
+{
+    const int n = p.nseeds, q = p.seed_q;
+    u32 v = 0;
+    for (int j = 0; j < q; j++) v = (v << 2) | base_at(hi, lo, (seed - 1) + n * j);
+    for (int j = 0; j < 8 - q; j++) v = (v << 4) | 3u;
+    for (int j = q - 1; j >= 0; j--) v = (v << 2) | base_at(hi, lo, p.K - 1 - ((seed - 1) + n * j));
+    return v;
+}
+
+__device__ __forceinline__ u32 rc_code(u32 c)      // HTS:1904-1911
+{
+    u32 r = __brev(c);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    return ~r;
+}
+
+__global__ __launch_bounds__(256) void k_seed_codes(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ reps,
+                                                    u64 n_reps, int seed, u64 *__restrict__ out)
+{
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reps) return;
+    const u32 g = reps[r];
+    u64 hi, lo;
+    load_window(p, pk, g, hi, lo);
+    const u32 fw = seed_code(p, hi, lo, seed), rc = rc_code(fw);
+    out[r] = ((u64)(fw <= rc ? fw : rc) << 32) | g;          // canonical code (HTS:2732-2744)
+}
+
+struct Mism { u64 hi, lo; };
+__device__ __forceinline__ Mism mism_of(u64 ah, u64 al, u64 bh, u64 bl)
+{
+    Mism m;
+    const u64 xh = ah ^ bh, xl = al ^ bl;
+    m.hi = (xh | (xh >> 1)) & M55;
+    m.lo = (xl | (xl >> 1)) & M55;
+    return m;
+}
+
+// CompareAndReport (HTS:2138-2265) on one orientation's mismatch mask.  Returns meta or 0xFFFFFFFF.
+__device__ __forceinline__ u32 judge(const DevParams &p, Mism m, int seed, u32 dir)
+{
+    const u64 eh = m.hi & ~p.seedmask_hi[seed - 1], el = m.lo & ~p.seedmask_lo[seed - 1];
+    const int nerr = __popcll(eh) + __popcll(el);
+    if (nerr == 0 || nerr > p.d) return 0xFFFFFFFFu;
+    for (int s = 0; s < seed - 1; s++)                          // reported by the first seed that matches exactly (HTS:2222-2232)
+        if (((m.hi & p.seedmask_hi[s]) | (m.lo & p.seedmask_lo[s])) == 0) return 0xFFFFFFFFu;
+    u32 off[3] = {0, 0, 0};
+    int k = 0;
+    u64 t = eh;
+    while (t) { const int lz = __clzll((long long)t); off[k++] = (u32)(lz >> 1) + 1u; t &= ~(0x8000000000000000ull >> lz); }
+    t = el;
+    while (t) { const int lz = __clzll((long long)t); off[k++] = 32u + (u32)(lz >> 1) + 1u; t &= ~(0x8000000000000000ull >> lz); }
+    return meta_pack(dir, off[0], off[1], off[2], (u32)(seed - 1), 0, 0);
+}
+
+__device__ __forceinline__ void emit_pair(PairRec *__restrict__ pairs, u64 cap, DevCounters *ctr, u32 p1, u32 p2, u32 meta)
+{
+    const unsigned long long at = atomicAdd(&ctr->n_pairs, 1ull);
+    if (at < cap) { pairs[at].p1 = p1; pairs[at].p2 = p2; pairs[at].meta = meta; }
+}
+
+// One thread per representative in (canonical code, position) order.  It is compared with every
+// EARLIER representative of its equal-code run (HTS:2753-2762: k-mer 1 is the later one).
+// The orientation is the one in which the seed positions agree; a palindromic code agrees in both,
+// and the reference then compares both ways and meets every earlier entry twice (Q1, HTS:2769-2792).
+__global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ codes, u64 n_reps,
+                                                int seed, PairRec *__restrict__ pairs, u64 cap, DevCounters *ctr)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_reps) return;
+    const u64 ci = codes[i];
+    const u32 code = (u32)(ci >> 32), gi = (u32)ci;
+    if (i == 0 || (u32)(codes[i - 1] >> 32) != code) {
+        if (rc_code(code) != code) return;                 // run head, nothing earlier to meet
+    }
+    const bool pal = rc_code(code) == code;
+    u64 ih, il;
+    load_window(p, pk, gi, ih, il);
+    const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
+    unsigned long long ncand = 0;
+    if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
+        u64 rh, rl;
+        rc_window(p.K, ih, il, rh, rl);
+        const u32 meta = judge(p, mism_of(ih, il, rh, rl), seed, 1);
+        ncand++;
+        if (meta != 0xFFFFFFFFu) emit_pair(pairs, cap, ctr, gi, gi, meta | (1u << 24));
+    }
+    for (u64 j = i; j-- > 0;) {
+        const u64 cj = codes[j];
+        if ((u32)(cj >> 32) != code) break;
+        const u32 gj = (u32)cj;
+        u64 jh, jl, rh, rl;
+        load_window(p, pk, gj, jh, jl);
+        rc_window(p.K, jh, jl, rh, rl);
+        const Mism same = mism_of(ih, il, jh, jl), rev = mism_of(ih, il, rh, rl);
+        const bool same_ok = ((same.hi & smh) | (same.lo & sml)) == 0;
+        if (pal) {
+            ncand += 4;
+            const u32 m0 = judge(p, same, seed, 0);
+            if (m0 != 0xFFFFFFFFu) { emit_pair(pairs, cap, ctr, gi, gj, m0); emit_pair(pairs, cap, ctr, gi, gj, m0 | (1u << 25)); }
+            const u32 m1 = judge(p, rev, seed, 1);
+            if (m1 != 0xFFFFFFFFu) { emit_pair(pairs, cap, ctr, gi, gj, m1 | (1u << 24)); emit_pair(pairs, cap, ctr, gi, gj, m1 | (1u << 24) | (1u << 25)); }
+        } else {
+            ncand++;
+            const u32 meta = same_ok ? judge(p, same, seed, 0) : judge(p, rev, seed, 1);
+            if (meta != 0xFFFFFFFFu) emit_pair(pairs, cap, ctr, gi, gj, meta);
+        }
+    }
+    if (ncand) atomicAdd(&ctr->n_candidates, ncand);
+}
+
+// ------------------------------------------------------------------ directed items
+// Each pair gives item 1->2 and item 2->1; for a reverse homology the 2->1 offsets are mirrored
+// and re-sorted (HTS:1022-1103).
+__global__ __launch_bounds__(256) void k_items_expand(DevParams p, const PairRec *__restrict__ pairs, u64 n_pairs,
+                                                      u64 *__restrict__ item_key, u32 *__restrict__ item_meta)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    const PairRec r = pairs[i];
+    item_key[2 * i] = ((u64)r.p1 << 32) | r.p2;
+    item_meta[2 * i] = r.meta;
+    u32 m2 = r.meta;
+    if (r.meta & META_DIR) {
+        const u32 o1 = meta_o1(r.meta), o2 = meta_o2(r.meta), o3 = meta_o3(r.meta), K = (u32)p.K;
+        u32 n1, n2 = 0, n3 = 0;
+        if (o2 == 0) n1 = K - o1 + 1;
+        else if (o3 == 0) { n1 = K - o2 + 1; n2 = K - o1 + 1; }
+        else { n1 = K - o3 + 1; n2 = K - o2 + 1; n3 = K - o1 + 1; }
+        m2 = (r.meta & ~(META_MATCH_MASK & ~1u)) | (n1 << 1) | (n2 << 8) | (n3 << 15);
+    }
+    item_key[2 * i + 1] = ((u64)r.p2 << 32) | r.p1;
+    item_meta[2 * i + 1] = m2;
+}
+
+__global__ __launch_bounds__(256) void k_node_flags(const u64 *__restrict__ item_key, u64 m, u32 *__restrict__ head_flag,
+                                                    DevCounters *ctr)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const u64 k = item_key[i];
+    const bool head = (i == 0) || (item_key[i - 1] >> 32) != (k >> 32);
+    head_flag[i] = head ? 1u : 0u;
+    if (i > 0 && item_key[i - 1] == k) atomicAdd(&ctr->n_dirty, 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_node_starts(const u32 *__restrict__ head_flag, const u64 *__restrict__ node_of_excl, u64 m,
+                                                     u32 *__restrict__ node_start)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    if (head_flag[i]) node_start[node_of_excl[i]] = (u32)i;
+}
+
+__device__ __forceinline__ bool same_window(const DevParams &p, u64 a, u64 b)
+{
+    if (!p.any_windowed) return true;
+    const u32 c = find_contig(p, a);
+    const u32 w = p.ctg_window[c];
+    if (!w) return true;
+    const u64 s = p.ctg_gstart[c];
+    return (a - s) / w == (b - s) / w;
+}
+
+// looks in node `nd` for the item (src, tgt) whose dir/offsets equal `want`
+__device__ __forceinline__ bool find_item(const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
+                                          const u32 *__restrict__ node_start, u32 nd, u64 key, u32 want)
+{
+    u32 a = node_start[nd], b = node_start[nd + 1];
+    while (a < b) {
+        const u32 mid = (a + b) >> 1;
+        if (item_key[mid] < key) a = mid + 1; else b = mid;
+    }
+    const u32 end = node_start[nd + 1];
+    for (; a < end && item_key[a] == key; a++)
+        if ((item_meta[a] & META_MATCH_MASK) == want) return true;
+    return false;
+}
+
+// Diagonal block merge (HTS:1203-1270) for lists without tied targets: an item is absorbed when the
+// list one base upstream holds its diagonal predecessor (target one base back along its strand,
+// same direction, every offset one larger); a surviving item's block length is the length of the
+// diagonal run it heads.  Lists with tied targets are redone by the host in the reference's order.
+__global__ __launch_bounds__(256) void k_chain(DevParams p, const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
+                                               const u32 *__restrict__ head_flag, const u64 *__restrict__ node_of_excl,
+                                               const u32 *__restrict__ node_start, u32 n_nodes, u64 m, int16_t *__restrict__ blen)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const u32 nd = (u32)(node_of_excl[i] + head_flag[i] - 1);
+    const u64 key = item_key[i];
+    const u64 src = key >> 32, tgt = key & 0xFFFFFFFFull;
+    const u32 meta = item_meta[i];
+    const u32 dir = meta & 1u, o1 = meta_o1(meta), o2 = meta_o2(meta), o3 = meta_o3(meta);
+    // predecessor?
+    if (nd > 0 && src > 0 && (item_key[node_start[nd - 1]] >> 32) == src - 1 && same_window(p, src - 1, src)) {
+        const bool can = dir ? true : (tgt > 0);
+        if (can) {
+            const u64 pt = dir ? tgt + 1 : tgt - 1;
+            const u32 want = meta_pack(dir, o1 + 1, o2 ? o2 + 1 : 0, o3 ? o3 + 1 : 0, 0, 0, 0);
+            if (o1 + 1 <= (u32)p.K && find_item(item_key, item_meta, node_start, nd - 1, ((src - 1) << 32) | pt, want)) {
+                blen[i] = -1;
+                return;
+            }
+        }
+    }
+    u32 L = 1;
+    for (;;) {
+        if (o1 <= L) break;                                          // offset1 - distance must stay >= 1
+        const u32 nn = nd + L;
+        if (nn >= n_nodes) break;
+        if ((item_key[node_start[nn]] >> 32) != src + L) break;      // next position has no list
+        if (!same_window(p, src, src + L)) break;
+        if (dir && tgt < L) break;
+        const u64 nt = dir ? tgt - L : tgt + L;
+        const u32 want = meta_pack(dir, o1 - L, o2 ? o2 - L : 0, o3 ? o3 - L : 0, 0, 0, 0);
+        if (!find_item(item_key, item_meta, node_start, nn, ((src + L) << 32) | nt, want)) break;
+        L++;
+    }
+    blen[i] = (int16_t)L;
+}
+
+// ------------------------------------------------------------------ launch wrappers
+static inline dim3 grid_for(u64 n) { return dim3((unsigned)((n + 255) / 256)); }
+
+void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr)
+{
+    hipLaunchKernelGGL(k_pack, grid_for(p.n_words + 4), dim3(256), 0, s, p, raw, pk, bad, ctr);
+}
+void launch_kmer_count(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 n_blocks)
+{
+    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, p, bad, block_counts);
+}
+void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 n_blocks,
+                      u64 *key_hi, u64 *key_lo, u32 *gpos)
+{
+    hipLaunchKernelGGL(k_kmer_emit, dim3(n_blocks), dim3(256), 0, s, p, pk, bad, block_off, key_hi, key_lo, gpos);
+}
+void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr)
+{
+    hipLaunchKernelGGL(k_contig_check, grid_for(p.n_contigs), dim3(256), 0, s, p, gpos_by_position, n, ctr);
+}
+void launch_class_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
+                        DevCounters *ctr)
+{
+    if (n) hipLaunchKernelGGL(k_class_count, grid_for(n), dim3(256), 0, s, p, pk, hi, lo, gpos, n, ctr);
+}
+void launch_class_emit(hipStream_t s, const DevParams &p, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n, u32 *repmask,
+                       u64 *cls, u32 *cls_fill)
+{
+    if (n) hipLaunchKernelGGL(k_class_emit, grid_for(n), dim3(256), 0, s, p, hi, lo, gpos, n, repmask, cls, cls_fill);
+}
+void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks)
+{
+    hipLaunchKernelGGL(k_bitmap_count, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_counts);
+}
+void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out)
+{
+    hipLaunchKernelGGL(k_bitmap_emit, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_off, out);
+}
+void launch_class_info(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, u64 n, const u64 *cls,
+                       u32 n_cls, const DevCounters *ctr, u32 *cls_m, u32 *cls_flags, u32 *cls_entries)
+{
+    if (n_cls) hipLaunchKernelGGL(k_class_info, grid_for(n_cls), dim3(256), 0, s, p, pk, hi, lo, n, cls, n_cls, ctr, cls_m, cls_flags, cls_entries);
+}
+void launch_class_entries(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, const u64 *cls, u32 n_cls,
+                          const u32 *cls_m, const u32 *cls_flags, const u64 *ent_off, u32 *ent, u8 *ent_dir)
+{
+    if (n_cls) hipLaunchKernelGGL(k_class_entries, grid_for(n_cls), dim3(256), 0, s, p, pk, gpos, cls, n_cls, cls_m, cls_flags, ent_off, ent, ent_dir);
+}
+void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off, const u32 *ent,
+                        const u8 *ent_dir, u8 *merge_prev)
+{
+    if (n_cls) hipLaunchKernelGGL(k_class_merge, grid_for(n_cls), dim3(256), 0, s, cls, n_cls, cls_entries, ent_off, ent, ent_dir, merge_prev);
+}
+void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out)
+{
+    if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
+}
+void launch_verify(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed, PairRec *pairs, u64 cap,
+                   DevCounters *ctr)
+{
+    if (n_reps) hipLaunchKernelGGL(k_verify, grid_for(n_reps), dim3(256), 0, s, p, pk, codes, n_reps, seed, pairs, cap, ctr);
+}
+void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta)
+{
+    if (n_pairs) hipLaunchKernelGGL(k_items_expand, grid_for(n_pairs), dim3(256), 0, s, p, pairs, n_pairs, item_key, item_meta);
+}
+void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr)
+{
+    if (m) hipLaunchKernelGGL(k_node_flags, grid_for(m), dim3(256), 0, s, item_key, m, head_flag, ctr);
+}
+void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start)
+{
+    if (m) hipLaunchKernelGGL(k_node_starts, grid_for(m), dim3(256), 0, s, head_flag, node_of_excl, m, node_start);
+}
+void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u32 *head_flag,
+                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, int16_t *blen)
+{
+    if (m) hipLaunchKernelGGL(k_chain, grid_for(m), dim3(256), 0, s, p, item_key, item_meta, head_flag, node_of_excl, node_start, n_nodes, m, blen);
+}
+
+}  // namespace cora

@@ -1,0 +1,84 @@
+// kernels.hpp -- device-side parameters and launch wrappers of the homology-table
+// pipeline (kernels.hip).  HTS = /root/reference/homTable_setup.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cora {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+// Everything a kernel needs to know about the run; passed by value.
+struct DevParams {
+    int K, d, nseeds;
+    int seed_q;               // bases per seed half (8, or K/(2(d+1)) for short read-mers, HTS:2056)
+    u32 line_width;           // FASTA bases per line
+    u32 n_contigs;
+    u64 G;                    // padded length of the global coordinate (multiple of 64)
+    u64 n_words;              // G / 32
+    u64 image_bytes;
+    u64 kmask_lo;             // keeps the top 2*(K-32) bits of the low window word
+    u64 seedmask_hi[4], seedmask_lo[4];   // one bit per base (bit 62-2i of word i/32) for seed s = index+1
+    u32 any_windowed;         // d == 3 and some contig is compacted in 50 Mbp windows (HTS:2852-2856)
+    u8 sig2[16];              // physical group of (first,last) base pair
+    const u64 *ctg_gstart;    // [n_contigs+1] start of each contig in the global coordinate (last = G)
+    const u32 *ctg_len;       // [n_contigs]
+    const u64 *ctg_off;       // [n_contigs] file offset of the first base
+    const u32 *ctg_window;    // [n_contigs] 0 or the window length
+};
+
+// pair record meta / item meta bit layout
+//   bit 0      dir
+//   bits 1-7   off1, 8-14 off2, 15-21 off3   (1-based mismatch offsets, 0 = none)
+//   bits 22-23 seed-1, bit 24 palindrome pass, bit 25 duplicate index (Q1)
+constexpr u32 META_DIR = 1u;
+__host__ __device__ inline u32 meta_pack(u32 dir, u32 o1, u32 o2, u32 o3, u32 seed0, u32 pass, u32 dup)
+{
+    return dir | (o1 << 1) | (o2 << 8) | (o3 << 15) | (seed0 << 22) | (pass << 24) | (dup << 25);
+}
+__host__ __device__ inline u32 meta_o1(u32 m) { return (m >> 1) & 127u; }
+__host__ __device__ inline u32 meta_o2(u32 m) { return (m >> 8) & 127u; }
+__host__ __device__ inline u32 meta_o3(u32 m) { return (m >> 15) & 127u; }
+__host__ __device__ inline u32 meta_seed0(u32 m) { return (m >> 22) & 3u; }
+__host__ __device__ inline u32 meta_pass(u32 m) { return (m >> 24) & 1u; }
+__host__ __device__ inline u32 meta_dup(u32 m) { return (m >> 25) & 1u; }
+constexpr u32 META_MATCH_MASK = (1u << 22) - 1u;   // dir + offsets: what block merging compares
+
+struct PairRec { u32 p1, p2, meta; };
+
+// counters block kept on the device for one run
+struct DevCounters {
+    unsigned long long n_reps, n_nonsingle, first_singleton_key, n_pairs, n_candidates, n_dirty, format_errors;
+    unsigned long long empty_contigs;
+};
+
+// ---- launch wrappers (all asynchronous on stream s) ----
+void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr);
+void launch_kmer_count(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 n_blocks);
+void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
+                      u32 n_blocks, u64 *key_hi, u64 *key_lo, u32 *gpos);
+void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);
+void launch_class_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
+                        u64 n, DevCounters *ctr);
+void launch_class_emit(hipStream_t s, const DevParams &p, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
+                       u32 *repmask, u64 *cls /* rep<<32|start */, u32 *cls_fill);
+void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks);
+void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out);
+void launch_class_info(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, u64 n,
+                       const u64 *cls, u32 n_cls, const DevCounters *ctr, u32 *cls_m, u32 *cls_flags, u32 *cls_entries);
+void launch_class_entries(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, const u64 *cls, u32 n_cls,
+                          const u32 *cls_m, const u32 *cls_flags, const u64 *ent_off, u32 *ent /* gpos */, u8 *ent_dir);
+void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off,
+                        const u32 *ent, const u8 *ent_dir, u8 *merge_prev);
+void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out);
+void launch_verify(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed,
+                   PairRec *pairs, u64 cap, DevCounters *ctr);
+void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta);
+void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr);
+void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start);
+void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u32 *head_flag,
+                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, int16_t *blen);
+
+}  // namespace cora

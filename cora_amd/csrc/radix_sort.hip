@@ -1,0 +1,380 @@
+// radix_sort.hip -- stable LSD radix sort (8-bit digits) and prefix scans, written for
+// CDNA4 (gfx950): 64-lane wavefronts, ballot-based match-any ranking, records staged
+// through LDS so that every global store of a pass is a run of consecutive addresses.
+//
+// One pass = three small kernels over the [tiles][256] digit histogram plus the scatter:
+//   rs_hist      per-tile digit histogram                      (reads the digit word)
+//   rs_colsum / rs_chunkscan / rs_colscan   digit-major exclusive scan, row-coalesced
+//   rs_scatter   rank in LDS, stage, write                     (reads + writes every array)
+// HBM traffic per pass and record: 8 B (hist) + 2 x record bytes (scatter).
+#include "radix_sort.hpp"
+
+namespace cora {
+
+#define RS_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32 *lds_waves /*[4]*/, u32 *total)
+{
+    // 256 threads, one value each; returns the exclusive prefix of v over threadIdx.x
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds_waves[wv] = x;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { u32 s = lds_waves[w]; if (w < wv) base += s; tot += s; }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist(const u64 *__restrict__ w, u64 n, int shift, u32 mask,
+                                                       u32 *__restrict__ tile_hist)
+{
+    __shared__ u32 h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_IPT; k++) {
+        u64 idx = base + (u64)k * RS_THREADS + tid;
+        if (idx < n) atomicAdd(&h[(u32)(w[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    tile_hist[(size_t)blockIdx.x * 256 + tid] = h[tid];
+}
+
+__global__ __launch_bounds__(256) void rs_colsum(const u32 *__restrict__ tile_hist, u32 tiles, u32 *__restrict__ chunk_sums)
+{
+    const u32 t0 = blockIdx.x * RS_CHUNK_TILES;
+    const u32 t1 = min(tiles, t0 + RS_CHUNK_TILES);
+    u32 s = 0;
+    for (u32 t = t0; t < t1; t++) s += tile_hist[(size_t)t * 256 + threadIdx.x];
+    chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void rs_chunkscan(u32 *__restrict__ chunk_sums, u32 chunks)
+{
+    __shared__ u32 wsum[4];
+    const int d = threadIdx.x;
+    u32 run = 0;
+    for (u32 c = 0; c < chunks; c++) {
+        u32 v = chunk_sums[(size_t)c * 256 + d];
+        chunk_sums[(size_t)c * 256 + d] = run;
+        run += v;
+    }
+    u32 base = block_exclusive_scan_256(run, wsum, nullptr);
+    for (u32 c = 0; c < chunks; c++) chunk_sums[(size_t)c * 256 + d] += base;
+}
+
+__global__ __launch_bounds__(256) void rs_colscan(u32 *__restrict__ tile_hist, u32 tiles, const u32 *__restrict__ chunk_sums)
+{
+    const u32 t0 = blockIdx.x * RS_CHUNK_TILES;
+    const u32 t1 = min(tiles, t0 + RS_CHUNK_TILES);
+    u32 run = chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x];
+    for (u32 t = t0; t < t1; t++) {
+        u32 v = tile_hist[(size_t)t * 256 + threadIdx.x];
+        tile_hist[(size_t)t * 256 + threadIdx.x] = run;
+        run += v;
+    }
+}
+
+// The scatter.  Thread (wave w, lane l) owns records base + w*64*IPT + r*64 + l, r = 0..IPT-1,
+// so that (wave, round, lane) order is the input order: ranks assigned in that order keep
+// the sort stable.
+template <bool HAS_B, bool HAS_C, bool DIG_B>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__ a_in, const u64 *__restrict__ b_in,
+                                                          const u32 *__restrict__ c_in, u64 *__restrict__ a_out,
+                                                          u64 *__restrict__ b_out, u32 *__restrict__ c_out, u64 n,
+                                                          int shift, u32 mask, const u32 *__restrict__ tile_off)
+{
+    __shared__ u64 stage[RS_TILE];          // 32 KiB
+    __shared__ u32 wcnt[4][256];            // per-wave digit counters, then per-wave digit bases
+    __shared__ u32 delta[256];              // global offset of the digit's run minus its local start
+    __shared__ u32 wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+    const u32 count = (u32)min((u64)RS_TILE, n - base);
+    const u64 *dig_in = DIG_B ? b_in : a_in;
+    const u64 *oth_in = DIG_B ? a_in : b_in;
+    u64 *dig_out = DIG_B ? b_out : a_out;
+    u64 *oth_out = DIG_B ? a_out : b_out;
+
+    u64 kw[RS_IPT];
+    const u32 l0 = (u32)wv * 64 * RS_IPT + lane;      // local index of round 0
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        u32 li = l0 + r * 64;
+        kw[r] = (li < count) ? dig_in[base + li] : 0;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
+    __syncthreads();
+
+    u32 lpos[RS_IPT];
+    const u64 lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        const bool valid = (l0 + r * 64) < count;
+        const u32 d = (u32)(kw[r] >> shift) & mask;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 cnt = (u32)__popcll(peers);
+        const u32 below = (u32)__popcll(peers & lt_mask);
+        const int leader = peers ? (__ffsll((long long)peers) - 1) : lane;
+        u32 prev = 0;
+        if (valid && lane == leader) { prev = wcnt[wv][d]; wcnt[wv][d] = prev + cnt; }
+        prev = __shfl(prev, leader, 64);
+        lpos[r] = prev + below;               // rank within (wave, digit) so far
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        const u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+        const u32 start = block_exclusive_scan_256(c0 + c1 + c2 + c3, wsum, nullptr);
+        wcnt[0][tid] = start; wcnt[1][tid] = start + c0; wcnt[2][tid] = start + c0 + c1; wcnt[3][tid] = start + c0 + c1 + c2;
+        delta[tid] = tile_off[(size_t)blockIdx.x * 256 + tid] - start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        if ((l0 + r * 64) < count) {
+            const u32 d = (u32)(kw[r] >> shift) & mask;
+            lpos[r] += wcnt[wv][d];
+            stage[lpos[r]] = kw[r];
+        }
+    }
+    __syncthreads();
+    u32 dst[RS_IPT];
+#pragma unroll
+    for (int k = 0; k < RS_IPT; k++) {
+        const u32 i = k * RS_THREADS + tid;
+        if (i < count) {
+            const u64 v = stage[i];
+            dst[k] = delta[(u32)(v >> shift) & mask] + i;
+            dig_out[dst[k]] = v;
+        }
+    }
+    if (HAS_B) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) {
+            u32 li = l0 + r * 64;
+            if (li < count) stage[lpos[r]] = oth_in[base + li];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RS_IPT; k++) {
+            const u32 i = k * RS_THREADS + tid;
+            if (i < count) oth_out[dst[k]] = stage[i];
+        }
+    }
+    if (HAS_C) {
+        u32 *stage32 = reinterpret_cast<u32 *>(stage);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) {
+            u32 li = l0 + r * 64;
+            if (li < count) stage32[lpos[r]] = c_in[base + li];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RS_IPT; k++) {
+            const u32 i = k * RS_THREADS + tid;
+            if (i < count) c_out[dst[k]] = stage32[i];
+        }
+    }
+}
+
+int SortScratch::reserve(u64 n)
+{
+    size_t tiles = (size_t)((n + RS_TILE - 1) / RS_TILE);
+    size_t chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
+    if (tiles > cap_tiles) {
+        if (tile_hist) (void)hipFree(tile_hist);
+        tile_hist = nullptr; cap_tiles = 0;
+        RS_CHECK(hipMalloc(&tile_hist, tiles * 256 * sizeof(u32)));
+        cap_tiles = tiles;
+    }
+    if (chunks > cap_chunks) {
+        if (chunk_sums) (void)hipFree(chunk_sums);
+        chunk_sums = nullptr; cap_chunks = 0;
+        RS_CHECK(hipMalloc(&chunk_sums, chunks * 256 * sizeof(u32)));
+        cap_chunks = chunks;
+    }
+    if (!ev0) { RS_CHECK(hipEventCreate(&ev0)); RS_CHECK(hipEventCreate(&ev1)); }
+    return 0;
+}
+
+void SortScratch::release()
+{
+    if (tile_hist) (void)hipFree(tile_hist);
+    if (chunk_sums) (void)hipFree(chunk_sums);
+    if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+    tile_hist = nullptr; chunk_sums = nullptr; cap_tiles = cap_chunks = 0; ev0 = ev1 = nullptr;
+}
+
+template <bool HAS_B, bool HAS_C>
+static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
+                           int shift, u32 mask, const u32 *tile_off)
+{
+    if (HAS_B && dig_b)
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true>), dim3(tiles), dim3(RS_THREADS), 0, s, in.a, in.b, in.c, out.a, out.b,
+                           out.c, n, shift, mask, tile_off);
+    else
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false>), dim3(tiles), dim3(RS_THREADS), 0, s, in.a, in.b, in.c, out.a, out.b,
+                           out.c, n, shift, mask, tile_off);
+}
+
+int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi, SortScratch &scratch,
+               SortTiming *timing)
+{
+    if (n == 0 || bit_hi <= bit_lo) return 0;
+    if (n >= (1ull << 32)) return (int)hipErrorInvalidValue;      // u32 offsets inside the kernels
+    bit_lo &= ~7;
+    int rc = scratch.reserve(n);
+    if (rc) return rc;
+    const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
+    const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
+    const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
+    const u64 rec_bytes = 8 + (has_b ? 8 : 0) + (has_c ? 4 : 0);
+    for (int bit = bit_lo; bit < bit_hi; bit += 8) {
+        const int nbits = (bit_hi - bit) < 8 ? (bit_hi - bit) : 8;
+        const u32 mask = (1u << nbits) - 1u;
+        const bool dig_b = has_b && bit < 64;
+        const int shift = has_b ? (bit & 63) : bit;
+        const u64 *word = dig_b ? keys.b : keys.a;
+        hipLaunchKernelGGL(rs_hist, dim3(tiles), dim3(RS_THREADS), 0, s, word, n, shift, mask, scratch.tile_hist);
+        hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, scratch.chunk_sums);
+        hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(256), 0, s, scratch.chunk_sums, chunks);
+        hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, scratch.chunk_sums);
+        if (timing && timing->enabled) RS_CHECK(hipEventRecord(scratch.ev0, s));
+        if (has_b) {
+            if (has_c) launch_scatter<true, true>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
+            else launch_scatter<true, false>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
+        } else {
+            if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
+            else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
+        }
+        if (timing && timing->enabled) {
+            RS_CHECK(hipEventRecord(scratch.ev1, s));
+            RS_CHECK(hipEventSynchronize(scratch.ev1));
+            float ms = 0.f;
+            RS_CHECK(hipEventElapsedTime(&ms, scratch.ev0, scratch.ev1));
+            timing->scatter_ms += ms;
+            timing->scatter_launches += 1;
+            timing->scatter_bytes += 2 * rec_bytes * n;
+        }
+        SortArrays t = keys; keys = tmp; tmp = t;
+    }
+    RS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// exclusive scan u32 -> u64, chunks of 4096 per workgroup, recursive over chunk sums
+// ------------------------------------------------------------------------------------
+constexpr int SC_IPT = 16;
+constexpr int SC_CHUNK = 256 * SC_IPT;
+
+__device__ __forceinline__ u64 block_exclusive_scan_256_u64(u64 v, u64 *lds_waves, u64 *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u64 x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u64 y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds_waves[wv] = x;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { u64 s = lds_waves[w]; if (w < wv) base += s; tot += s; }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void sc_reduce(const TIN *__restrict__ in, u64 n, u64 *__restrict__ sums)
+{
+    __shared__ u64 ws[4];
+    const u64 base = (u64)blockIdx.x * SC_CHUNK + (u64)threadIdx.x * SC_IPT;
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_IPT; k++) if (base + k < n) s += in[base + k];
+    u64 tot;
+    (void)block_exclusive_scan_256_u64(s, ws, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void sc_scan(const TIN *in, u64 *out, u64 n,
+                                               const u64 *__restrict__ chunk_off, u64 *__restrict__ total)
+{
+    __shared__ u64 ws[4];
+    const u64 base = (u64)blockIdx.x * SC_CHUNK + (u64)threadIdx.x * SC_IPT;
+    u64 v[SC_IPT];
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_IPT; k++) { v[k] = (base + k < n) ? (u64)in[base + k] : 0; s += v[k]; }
+    u64 tot;
+    u64 pre = block_exclusive_scan_256_u64(s, ws, &tot) + (chunk_off ? chunk_off[blockIdx.x] : 0);
+#pragma unroll
+    for (int k = 0; k < SC_IPT; k++) { if (base + k < n) out[base + k] = pre; pre += v[k]; }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total = pre;
+}
+
+size_t scan_scratch_elems(u64 n)
+{
+    size_t tot = 0;
+    u64 m = n;
+    while (m > 1) { m = (m + SC_CHUNK - 1) / SC_CHUNK; tot += (size_t)m + 1; if (m == 1) break; }
+    return tot + 8;
+}
+
+static int scan_u64_inplace(hipStream_t s, u64 *data, u64 n, u64 *scratch);
+
+template <typename TIN>
+static int scan_impl(hipStream_t s, const TIN *in, u64 *out, u64 n, u64 *scratch, u64 *total_dev)
+{
+    if (n == 0) { if (total_dev) RS_CHECK(hipMemsetAsync(total_dev, 0, sizeof(u64), s)); return 0; }
+    const u64 chunks = (n + SC_CHUNK - 1) / SC_CHUNK;
+    if (chunks == 1) {
+        hipLaunchKernelGGL((sc_scan<TIN>), dim3(1), dim3(256), 0, s, in, out, n, (const u64 *)nullptr, total_dev);
+        return 0;
+    }
+    u64 *sums = scratch;
+    hipLaunchKernelGGL((sc_reduce<TIN>), dim3((u32)chunks), dim3(256), 0, s, in, n, sums);
+    int rc = scan_u64_inplace(s, sums, chunks, scratch + chunks);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sc_scan<TIN>), dim3((u32)chunks), dim3(256), 0, s, in, out, n, (const u64 *)sums, total_dev);
+    return 0;
+}
+
+static int scan_u64_inplace(hipStream_t s, u64 *data, u64 n, u64 *scratch)
+{
+    return scan_impl<u64>(s, data, data, n, scratch, nullptr);
+}
+
+int exclusive_scan_u32_to_u64(hipStream_t s, const u32 *in, u64 *out, u64 n, u64 *scratch_dev, u64 *total_dev)
+{
+    int rc = scan_impl<u32>(s, in, out, n, scratch_dev, total_dev);
+    if (rc) return rc;
+    RS_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace cora

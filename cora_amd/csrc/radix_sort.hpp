@@ -1,0 +1,55 @@
+// radix_sort.hpp -- LDS-staged stable LSD radix sort and prefix scans for gfx950.
+// Host-side launch interface; kernels are in radix_sort.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cora {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// A record set in structure-of-arrays form: a (u64, always), b (u64, optional
+// low key word), c (u32, optional payload).  The logical key is a:b (128 bit)
+// when b is present, else a (64 bit).
+struct SortArrays {
+    u64 *a = nullptr;
+    u64 *b = nullptr;
+    u32 *c = nullptr;
+};
+
+struct SortTiming {          // accumulated over calls; events are created lazily
+    float scatter_ms = 0.f;  // time inside scatter launches
+    u32 scatter_launches = 0;
+    u64 scatter_bytes = 0;   // algorithmic bytes: every record read once and written once per pass
+    bool enabled = false;
+};
+
+// Scratch for the per-tile digit histograms (grown on demand, owned by caller).
+struct SortScratch {
+    u32 *tile_hist = nullptr;    // [tiles][256]
+    u32 *chunk_sums = nullptr;   // [chunks][256]
+    size_t cap_tiles = 0, cap_chunks = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int reserve(u64 n);
+    void release();
+};
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_IPT = 16;
+constexpr int RS_TILE = RS_THREADS * RS_IPT;      // 4096 records per workgroup
+constexpr int RS_CHUNK_TILES = 128;               // tiles per column-scan workgroup
+
+// Sorts n records by key bits [bit_lo, bit_hi) (bit 0 = LSB of the logical key,
+// bit_lo is rounded down to a multiple of 8).  Stable.  `keys` and `tmp` are
+// ping-pong buffers of equal shape; on return `keys` names the sorted data
+// (the two structs are swapped after an odd number of passes).
+int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi,
+               SortScratch &scratch, SortTiming *timing);
+
+// out[i] = sum_{j<i} in[j]  (u32 in, u64 out); *total_dev (device u64) gets the grand total.
+// scratch_dev must hold at least scan_scratch_elems(n) u64.
+size_t scan_scratch_elems(u64 n);
+int exclusive_scan_u32_to_u64(hipStream_t s, const u32 *in, u64 *out, u64 n, u64 *scratch_dev, u64 *total_dev);
+
+}  // namespace cora

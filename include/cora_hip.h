@@ -1,0 +1,128 @@
+/*
+ * cora_hip.h -- C-ABI of libcora_hip.so, the MI355X (gfx950) homology-table
+ * builder that stands in for CORA's homTable_setup hot path.
+ *
+ * The reference has no FFI for this path: its boundary is the process
+ *   homTable_setup[_L] <ref.fa> <K> <physSplits> <ExactOut> <InexactOut>
+ *                      <parSplits> <EXACT|BOTH> <d> <FULL|...>
+ * (/root/reference/homTable_setup.cpp:2389-2405, called from cora.cpp:1586).
+ * The drop-in executable of the same name (cora_amd/csrc/hts_main.cpp) keeps
+ * that command line and the on-disk formats and calls the functions below.
+ * Plain C types only: pointers, sizes, integer status (0 = ok, otherwise the
+ * reference's exit code where one exists); no exceptions cross this seam.
+ * HTS = /root/reference/homTable_setup.cpp.
+ */
+#ifndef CORA_HIP_H
+#define CORA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORA_HIP_MAX_SEEDS 4
+
+/* One contig of the reference, as the loader needs it.
+ * Replaces the per-contig state of ConfigureRelatedParameters / ReadReference
+ * (HTS:144-202, 96-142): name order and length come from the .fai (columns 1-2),
+ * file_offset is where the contig's first base sits in the FASTA file image. */
+typedef struct cora_hip_contig {
+    uint64_t file_offset;   /* byte offset of the first base in the file image */
+    uint32_t length;        /* bases (from .fai column 2) */
+    uint32_t reserved;
+} cora_hip_contig;
+
+/* Run parameters (argv[2], argv[8], -DCHR_SHORT, and the two split files after
+ * parsing: HTS:2418-2460, 2295-2346). */
+typedef struct cora_hip_params {
+    int32_t K;                    /* read-mer length, 33..64 (HTS:2418-2424) */
+    int32_t d;                    /* Hamming radius 1..3 (HTS:2017-2021) */
+    int32_t chr_short;            /* 0: homTable_setup (1-byte contig ids), 1: homTable_setup_L (2-byte) */
+    int32_t line_width;           /* bases per FASTA line (HTS:155-166) */
+    int32_t n_groups;             /* physical splits p (first line of argv[3]) */
+    int32_t n_threads;            /* parallel splits t (first line of argv[6]) */
+    uint8_t sig2[16];             /* group (1..p) of 2-mer [4*first+last], codes A0 C1 G2 T3 (HTS:2292, 2503-2509) */
+    uint8_t sig4[256];            /* thread (1..t) of 4-mer token [64*c0+16*c1+4*c2+c3] (HTS:2291, 2327-2346) */
+} cora_hip_params;
+
+/* Per-run figures a caller may want to print or benchmark with. */
+typedef struct cora_hip_stats {
+    uint64_t genome_bases;        /* sum of contig lengths */
+    uint64_t kmers;               /* valid K-mer windows (Q4 rule applied, HTS:1954-1981) */
+    uint64_t representatives;     /* distinct canonical K-mers = marked positions (HTS:2573-2578) */
+    uint64_t exact_classes;       /* classes with >= 2 entries (HTS:336-347) */
+    uint64_t exact_nodes;         /* records in <Exact> after block merging (HTS:572-635) */
+    uint64_t candidate_pairs;     /* K-mer comparisons done, all seeds (HTS:2753-2762) */
+    uint64_t hom_pairs;           /* pair records reported (HTS:2234-2264) */
+    uint64_t inexact_items;       /* directed items before block merging (HTS:1022-1103) */
+    uint64_t inexact_nodes;       /* nodes written to <Inexact> (HTS:1353-1432) */
+    uint64_t dirty_nodes;         /* nodes with tied targets, finished by the exact-order host path */
+    uint64_t big_nodes;           /* nodes with > 16 items (std::sort's unstable regime, HTS:1368) */
+    /* timings of the last run, milliseconds (HIP events on the job's stream; host = wall) */
+    float ms_pack, ms_exact, ms_seeds, ms_items, ms_host_finish, ms_total;
+    float ms_sort_scatter;        /* time inside radix scatter launches (the dominant kernel) */
+    uint32_t n_sort_scatter;      /* number of those launches */
+    uint64_t sort_scatter_bytes;  /* algorithmic bytes those launches moved (read + write of every record) */
+} cora_hip_stats;
+
+typedef struct cora_hip_job cora_hip_job;   /* opaque */
+
+/* Library / device set-up.  device = HIP ordinal.  Fails (non-zero) when no
+ * gfx950 device is usable: there is no CPU fallback. */
+int cora_hip_init(int device);
+int cora_hip_shutdown(void);
+/* Text of the last error on the calling thread ("" if none). */
+const char *cora_hip_last_error(void);
+
+/* Creates a job for one reference.  Replaces main()'s set-up (HTS:2407-2471). */
+int cora_hip_job_create(const cora_hip_params *params, cora_hip_job **out);
+void cora_hip_job_destroy(cora_hip_job *job);
+
+/* Hands over the FASTA file image (host memory) and its contig table and
+ * copies the image to HBM.  Replaces ReadReference (HTS:96-142): the kernels
+ * read bases straight from the file image using the fixed line width, so the
+ * host does no per-base work. */
+int cora_hip_job_set_reference(cora_hip_job *job, const uint8_t *fasta_image, size_t image_bytes,
+                               const cora_hip_contig *contigs, int32_t n_contigs);
+
+/* Builds both tables from the HBM-resident image: 2-bit pack, canonical K-mers,
+ * radix sort, classes and representatives (HTS:2499-2640, 249-497), per-seed
+ * code sort + equal-run pair verification (HTS:2671-2800, 2138-2265), directed
+ * item sort and diagonal block merge (HTS:1022-1270), final ordering and
+ * serialisation (HTS:572-635, 1353-1432).  May be called repeatedly. */
+int cora_hip_job_run(cora_hip_job *job);
+
+/* The tables of the last run, in the reference's on-disk byte layout
+ * (F1/F2 of SURVEY.md section 8a); pointers stay valid until the next run or destroy. */
+int cora_hip_job_tables(const cora_hip_job *job,
+                        const uint8_t **exact, size_t *exact_bytes, uint64_t *exact_nodes,
+                        const uint8_t **inexact, size_t *inexact_bytes, uint64_t *inexact_nodes);
+int cora_hip_job_stats(const cora_hip_job *job, cora_hip_stats *out);
+
+/* ---- stage-level entry points (used by the parity tests and the benchmark) ---- */
+
+/* Stable LSD radix sort of n records on device memory, keyed on bits
+ * [bit_lo, bit_hi) of the 128-bit key (key_hi:key_lo); key_lo and val may be
+ * NULL.  All pointers are DEVICE pointers; tmp_* are same-sized scratch arrays.
+ * On return the sorted records are in the original arrays.  This is the
+ * kernel family behind every sort of the path (stands for the reference's
+ * unordered_map / std::sort uses: HTS:2516, 2681, 450, 1141). */
+int cora_hip_radix_sort(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val,
+                        uint64_t *tmp_hi, uint64_t *tmp_lo, uint32_t *tmp_val,
+                        uint64_t n, int bit_lo, int bit_hi);
+
+/* Host-buffer convenience wrappers for tests: copy in, run the kernels, copy out. */
+int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val, uint64_t n, int bit_lo, int bit_hi);
+/* 2-bit pack + validity of the reference image of a job (after set_reference):
+ * fills packed[ceil(G/32)] (base i of the padded global coordinate at bits
+ * 62-2*(i%32) of word i/32), bad[ceil(G/32)] (bit 31-(i%32)), and contig_start[n_contigs]. */
+int cora_hip_test_pack(cora_hip_job *job, uint64_t *packed, uint32_t *bad, uint64_t *contig_start, uint64_t *padded_len);
+/* Canonical keys of all valid windows, in position order (after set_reference). */
+int cora_hip_test_kmers(cora_hip_job *job, uint64_t *key_hi, uint64_t *key_lo, uint32_t *gpos, uint64_t cap, uint64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORA_HIP_H */

@@ -1,0 +1,161 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libcora_hip.so) and through the
+drop-in executable, against (1) tables written by the real reference binary (tests/golden),
+(2) the CPU oracle on seeded inputs, (3) numpy restatements of single stages.
+Bit-exact throughout: this path is integer/byte work."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from cora_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    hip.init(0)
+
+
+# ------------------------------------------------------------------ radix sort
+@pytest.mark.parametrize("n", [1, 63, 4095, 4096, 4097, 70001, 1_000_003])
+@pytest.mark.parametrize("shape", ["a", "ab", "ac", "abc"])
+def test_radix_sort_matches_numpy(n, shape):
+    rs = np.random.RandomState(n % 1000 + len(shape))
+    hi = rs.randint(0, 2 ** 62, size=n).astype(np.uint64) * np.uint64(3)
+    lo = rs.randint(0, 2 ** 62, size=n).astype(np.uint64) if "b" in shape else None
+    if n > 100:                      # force ties so that stability is exercised
+        hi[rs.randint(0, n, size=n // 3)] = hi[0]
+        if lo is not None:
+            lo[rs.randint(0, n, size=n // 2)] = lo[1]
+    val = np.arange(n, dtype=np.uint32) if "c" in shape else None
+    if lo is not None:
+        order = np.lexsort((lo, hi))
+    else:
+        order = np.argsort(hi, kind="stable")
+    want_hi = hi[order]
+    want_lo = lo[order] if lo is not None else None
+    hip.sort_host(hi, lo, val, 0, 128 if lo is not None else 64)
+    assert np.array_equal(hi, want_hi)
+    if lo is not None:
+        assert np.array_equal(lo, want_lo)
+    if val is not None:
+        assert np.array_equal(val, order.astype(np.uint32))      # stable: ties keep input order
+
+
+def test_radix_sort_partial_bits():
+    rs = np.random.RandomState(7)
+    n = 50_000
+    hi = rs.randint(0, 2 ** 40, size=n).astype(np.uint64)
+    val = np.arange(n, dtype=np.uint32)
+    key = (hi >> np.uint64(8)) & np.uint64(0xFFFFF)     # bits 8..28
+    order = np.argsort(key, kind="stable")
+    hip.sort_host(hi, None, val, 8, 28)
+    assert np.array_equal(val, order.astype(np.uint32))
+
+
+# ------------------------------------------------------------------ pack / keys vs numpy
+def _np_pack(contigs, G, starts):
+    code = np.full(G, 0, dtype=np.uint8)
+    bad = np.ones(G, dtype=np.uint8)
+    lut = np.full(256, 255, dtype=np.uint8)
+    for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[ch] = v
+    for (name, seq), st in zip(contigs, starts):
+        c = lut[seq]
+        st = int(st)
+        code[st:st + len(seq)] = np.where(c == 255, 0, c)
+        bad[st:st + len(seq)] = (c == 255)
+    return code, bad
+
+
+def test_pack_and_kmers_match_numpy(tmp_path):
+    rs = np.random.RandomState(3)
+    contigs = [("a", synth.random_seq(rs, 1000)), ("b", synth.random_seq(rs, 777)), ("c", synth.random_seq(rs, 64))]
+    contigs[0][1][100:130] = ord("N")
+    contigs[0][1][300:310] |= 0x20
+    contigs[1][1][777 - 51] = ord("N")              # last stretch exactly K long: no window (Q4)
+    contigs[2][1][5] = ord("R")
+    fa = str(tmp_path / "x.fa")
+    synth.write_fasta(fa, contigs, 60)
+    K = 50
+    job = hip.Job(K, 2, helpers.split_path("phys", 1), helpers.split_path("par", 1))
+    job.set_reference_file(fa)
+    packed, badw, starts, G = job.pack()
+    code, bad = _np_pack(contigs, G, starts)
+    got_code = np.zeros(G, dtype=np.uint8)
+    got_bad = np.zeros(G, dtype=np.uint8)
+    for i in range(32):
+        got_code[i::32] = ((packed >> np.uint64(62 - 2 * i)) & np.uint64(3)).astype(np.uint8)
+        got_bad[i::32] = ((badw >> np.uint32(31 - i)) & np.uint32(1)).astype(np.uint8)
+    assert np.array_equal(got_bad, bad)
+    assert np.array_equal(got_code[bad == 0], code[bad == 0])
+
+    hi, lo, gp = job.kmers()
+    # numpy / python restatement of the window rule and the canonical key
+    want = []
+    for (name, seq), st in zip(contigs, starts):
+        st = int(st)
+        L = len(seq)
+        b = bad[st:st + L]
+        for a in range(L - K + 1):
+            if b[a:a + K].any():
+                continue
+            if a + K == L and (a == 0 or b[a - 1]):
+                continue                                     # Q4
+            w = code[st + a:st + a + K]
+            fw = int("".join(str(x) for x in w), 4) << (2 * (64 - K))
+            rcw = (3 - w[::-1])
+            rc = int("".join(str(x) for x in rcw), 4) << (2 * (64 - K))
+            k = min(fw, rc)
+            want.append((k >> 64, k & (2 ** 64 - 1), st + a))
+    assert len(want) == len(gp)
+    assert [int(x) for x in gp] == [w[2] for w in want]
+    assert [int(x) for x in hi] == [w[0] for w in want]
+    assert [int(x) for x in lo] == [w[1] for w in want]
+    job.close()
+
+
+# ------------------------------------------------------------------ whole tables vs the real reference
+@pytest.mark.parametrize("name", sorted(helpers.MANIFEST["cases"]))
+def test_tables_match_reference_golden(name):
+    c, want = helpers.golden_case(name)
+    e, en, i, inn, st = hip.build_tables(helpers.input_path(c["input"]), c["K"], c["d"],
+                                         helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
+    assert en == c["exact_nodes"] and inn == c["inexact_nodes"], (en, inn, st)
+    assert e == helpers.read(os.path.join(want, "Exact")), "%s: Exact differs" % name
+    assert i == helpers.read(os.path.join(want, "Inexact")), "%s: Inexact differs" % name
+
+
+def test_executable_is_a_drop_in(tmp_path):
+    name = "syn_k47_d2_L"
+    c, want = helpers.golden_case(name)
+    exe = os.path.join(hip.BIN_DIR, "homTable_setup_L")
+    ex, inx, r = helpers.run_tool(exe, helpers.input_path(c["input"]), c["K"], c["d"], helpers.split_path("phys", c["p"]),
+                                  helpers.split_path("par", c["t"]), str(tmp_path / "sub" / "dir"))
+    assert r.returncode == 0, r.stdout
+    helpers.assert_same_tables(ex, inx, want, name)
+    assert os.path.exists(ex + "_preCompact_toDelete") and os.path.exists(inx + "_preCompact_toDelete_t1")
+    # argument errors keep the reference's exit codes (HTS:2392-2424)
+    assert subprocess.run([exe]).returncode == 19
+    bad = subprocess.run([exe, "x.fa", "70", "a", "b", "c", "d", "BOTH", "2", "FULL"], stdout=subprocess.DEVNULL)
+    assert bad.returncode == 65
+
+
+# ------------------------------------------------------------------ seeded inputs vs the oracle
+@pytest.mark.parametrize("seed,K,d,p,t", [(1, 50, 2, 1, 1), (2, 33, 1, 3, 2), (3, 64, 3, 2, 4), (4, 41, 3, 1, 8), (5, 58, 2, 10, 8)])
+def test_seeded_genomes_match_oracle(seed, K, d, p, t, tmp_path):
+    fams = [(400, 9, 0.02, 3), (150, 30, 0.01, 2), (90, 5, 0.0, 0)]
+    contigs = synth.genome_with_families(100 + seed, 150_000, fams, n_runs=[(5000, 70), (149_000, 3)], lower=[(8000, 500)], name="s%d" % seed)
+    contigs.append(("tail", synth.mutate(np.random.RandomState(seed), contigs[0][1][20_000:26_000], 0.01)))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, contigs, 70)
+    phys, par = helpers.split_path("phys", p), helpers.split_path("par", t)
+    oex, oinx = helpers.run_oracle(fa, K, d, phys, par, str(tmp_path / "oracle"))
+    e, en, i, inn, st = hip.build_tables(fa, K, d, phys, par)
+    assert e == helpers.read(oex)
+    assert i == helpers.read(oinx)
+    assert str(en) == helpers.read(oex + ".itemCount").decode().strip()
+    assert str(inn) == helpers.read(oinx + ".itemCount").decode().strip()
