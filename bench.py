@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Benchmark of the homology-table hot path (BASELINE.json: reference k-mers/s into the d=2 table).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one complete table build (2-bit pack -> canonical k-mers -> radix sort -> classes ->
+seeds -> pair verification -> block merge -> both tables as bytes) over a synthetic reference whose
+FASTA image is already resident in HBM when the timed region starts.  N=1 runs configs[1]: the
+chr20-sized (64 Mbp) synthetic contig, K=50, d=2.  For N>1 every rank builds the table of its own
+64 Mbp reference (weak scaling, no data-path collective); ranks synchronise only to time the job.
+One JSON line on rank 0."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(K, d, sample_bases, tmp):
+    """The real reference (oracle/_ref, kind 'reference') or the C oracle ('port') on a bounded
+    sample of the same workload, timed on this box's host cores."""
+    from cora_amd import synth
+    fa = os.path.join(tmp, "sample.fa")
+    contigs = synth.workload_chr20_like(20, sample_bases)
+    synth.write_fasta(fa, contigs, 60)
+    phys, par = os.path.join(tmp, "phys1.txt"), os.path.join(tmp, "par8.txt")
+    synth.write_round_robin_splits(phys, 2, 1)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "homTable_setup")
+    oracle_bin = os.path.join(ROOT, "oracle", "hts_oracle")
+    if os.path.exists(ref_bin):
+        kind, exe, threads = "reference", ref_bin, 8
+    else:
+        if not os.path.exists(oracle_bin):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "hts_oracle"], stdout=subprocess.DEVNULL)
+        kind, exe, threads = "port", oracle_bin, 1
+    synth.write_round_robin_splits(par, 4, threads)
+    env = dict(os.environ, OMP_DYNAMIC="false", OMP_NUM_THREADS=str(threads))
+    env.pop("OMP_THREAD_LIMIT", None)
+    out = os.path.join(tmp, "cpu")
+    os.makedirs(out, exist_ok=True)
+    cmd = [exe, fa, str(K), phys, os.path.join(out, "E"), os.path.join(out, "I"), par, "BOTH", str(d), "FULL"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dt = time.time() - t0
+    if r.returncode != 0:
+        return None
+    nonN = int(sum((s != ord("N")).sum() for _, s in contigs))
+    return {"value": nonN / dt, "unit": "k-mers/s", "cores": threads, "kind": kind,
+            "sample": "chr20_like generator at %d bp (K=%d d=%d, -p 1 -t %d), %.1f s wall" % (sample_bases, K, d, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bases", type=int, default=64_000_000, help="reference length (default: chr20-sized)")
+    ap.add_argument("--cpu-sample", type=int, default=2_500_000, help="bases of the CPU-baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from cora_amd import hip, synth
+    K, d = 50, 2
+    hip.init(local_rank)
+    tmp = tempfile.mkdtemp(prefix="cora_bench_")
+    phys, par = os.path.join(tmp, "phys10.txt"), os.path.join(tmp, "par8.txt")
+    synth.write_round_robin_splits(phys, 2, 10)      # cora's defaults: -p 10 -t 8
+    synth.write_round_robin_splits(par, 4, 8)
+    contigs = synth.workload_chr20_like(20 + rank, a.bases)
+    image, W, geom = synth.fasta_image(contigs, 60)
+    job = hip.Job(K, d, phys, par)
+    job.set_reference(image, W, geom)               # H2D copy: the image is HBM-resident from here on
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        job.run()
+    sync()
+    t0 = time.perf_counter()
+    sc_ms, sc_n, sc_bytes = 0.0, 0, 0
+    for _ in range(a.steps):
+        job.run()
+        st = job.stats()
+        sc_ms += st["ms_sort_scatter"]; sc_n += st["n_sort_scatter"]; sc_bytes += st["sort_scatter_bytes"]
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        kt = torch.tensor([float(st["kmers"])], device="cuda", dtype=torch.float64)
+        dist.all_reduce(kt, op=dist.ReduceOp.SUM)
+        kmers_all = float(kt.item())
+    else:
+        kmers_all = float(st["kmers"])
+
+    if rank == 0:
+        achieved = (sc_bytes / 1e9) / (sc_ms / 1e3) if sc_ms > 0 else 0.0
+        out = {
+            "metric": "ref k-mers/sec into homology table (d=2)", "value": kmers_all * a.steps / dt, "unit": "k-mers/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "chr20_like synthetic contig, %d bp per GPU, K=%d, d=%d, 60-column FASTA image resident in HBM; "
+                                   "output = both tables as bytes in host memory" % (a.bases, K, d),
+                       "kmers_per_gpu": int(st["kmers"]), "hom_pairs": int(st["hom_pairs"]), "inexact_nodes": int(st["inexact_nodes"]),
+                       "exact_nodes": int(st["exact_nodes"]), "parallelism": "1 reference per GPU" if world > 1 else "1 GPU"},
+            "stage_ms": {k: round(st[k], 3) for k in ("ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total")},
+            "roofline": {"bound": "hbm", "kernel": "rs_scatter (LSD radix scatter, all sorts of the path)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "launches_per_step": sc_n // max(1, a.steps), "avg_launch_ms": sc_ms / max(1, sc_n), "traffic": None},
+        }
+        cb = cpu_baseline(K, d, a.cpu_sample, tmp) if a.cpu_sample > 0 else None
+        out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    job.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <string.h>
+#include <thread>
 #include <tuple>
 
 namespace cora {
@@ -115,7 +116,7 @@ struct DItem {                                            // one directed item i
     std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> ord;
 };
 
-inline uint32_t base_of(const std::vector<uint64_t> &pk, uint64_t gp)
+inline uint32_t base_of(const View<uint64_t> &pk, uint64_t gp)
 {
     return (uint32_t)(pk[gp >> 5] >> (62 - 2 * (gp & 31))) & 3u;
 }
@@ -152,13 +153,13 @@ void emit_item(Writer &w, const HostGenome &g, int d, uint32_t tgt, uint32_t dir
 // F2 (HTS:1353-1432): per source position with a surviving item: chr,pos { dir chr pos off.. blockLen }* 0xFF,
 // items by decreasing block length through std::sort (HTS:1368; unstable above 16 items, which is why the
 // very same library routine is applied to the very same pre-order here).
-void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, const std::vector<uint64_t> &packed,
-                       std::vector<uint8_t> &out, FinishStats &st)
+static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResult &r, const View<uint64_t> &packed,
+                                    size_t node_begin, size_t node_end, std::vector<uint8_t> &out, FinishStats &st)
 {
     out.clear();
     Writer w{out, g.chr_short ? 2 : 1};
     st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
-    const size_t n_nodes = r.node_start.empty() ? 0 : r.node_start.size() - 1;
+    const size_t n_nodes = node_end;
     auto src_of = [&](size_t nd) { return (uint32_t)(r.key[r.node_start[nd]] >> 32); };
     auto same_win = [&](uint32_t a, uint32_t b, uint32_t ci) {
         const uint32_t wl = g.window[ci];
@@ -169,7 +170,7 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, const 
     for (int s = 1; s <= g.d + 1; s++) seed_signal_offsets(g.K, g.tmpl, s, sig_off[s - 1]);
 
     std::vector<std::pair<int16_t, uint32_t>> order;
-    size_t i = 0;
+    size_t i = node_begin;
     while (i < n_nodes) {
         // maximal run of consecutive source positions inside one compaction window
         const uint32_t s0 = src_of(i);
@@ -258,6 +259,53 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, const 
             if (header) { w.u8(0xFF); st.inexact_nodes++; }
         }
         i = j;
+    }
+}
+
+void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
+                       std::vector<uint8_t> &out, FinishStats &st, int n_threads)
+{
+    const size_t n_nodes = r.node_start.empty() ? 0 : r.node_start.size() - 1;
+    st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
+    out.clear();
+    if (n_nodes == 0) return;
+    auto src_of = [&](size_t nd) { return (uint32_t)(r.key[r.node_start[nd]] >> 32); };
+    // a thread's range must start where a run of consecutive source positions starts (runs never
+    // interact: HTS:1212 stops at the first position without a list)
+    auto run_starts_at = [&](size_t nd) {
+        if (nd == 0 || src_of(nd) != src_of(nd - 1) + 1) return true;
+        const uint32_t ci = g.contig_of(src_of(nd));
+        const uint32_t wl = g.window[ci];
+        return wl != 0 && (src_of(nd - 1) - g.gstart[ci]) / wl != (src_of(nd) - g.gstart[ci]) / wl;
+    };
+    int T = n_threads < 1 ? 1 : n_threads;
+    if (r.key.size() < 200000) T = 1;
+    std::vector<size_t> cut(1, 0);
+    for (int t = 1; t < T; t++) {
+        // split by items, not nodes, to balance
+        const uint64_t want_item = (uint64_t)r.key.size() * t / T;
+        size_t nd = (size_t)(std::upper_bound(r.node_start.p, r.node_start.p + n_nodes, (uint32_t)want_item) - r.node_start.p);
+        if (nd > 0) nd--;
+        while (nd < n_nodes && !run_starts_at(nd)) nd++;
+        if (nd > cut.back() && nd < n_nodes) cut.push_back(nd);
+    }
+    cut.push_back(n_nodes);
+    const size_t parts = cut.size() - 1;
+    std::vector<std::vector<uint8_t>> bufs(parts);
+    std::vector<FinishStats> sts(parts);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; k++)
+        th.emplace_back([&, k]() { serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k]); });
+    serialize_inexact_range(g, r, packed, cut[0], cut[1], bufs[0], sts[0]);
+    for (auto &x : th) x.join();
+    size_t total = 0;
+    for (auto &b : bufs) total += b.size();
+    out.resize(total);
+    size_t at = 0;
+    for (size_t k = 0; k < parts; k++) {
+        if (!bufs[k].empty()) memcpy(out.data() + at, bufs[k].data(), bufs[k].size());
+        at += bufs[k].size();
+        st.inexact_nodes += sts[k].inexact_nodes; st.dirty_nodes += sts[k].dirty_nodes; st.big_nodes += sts[k].big_nodes;
     }
 }
 

@@ -28,27 +28,37 @@ void seed_signal_offsets(int K, const char *tmpl, int seed, int off[6] /* so, eo
 // Which contigs the reference compacts in 50 Mbp windows (HTS:727-765, 1467-1479, 2845-2860).
 void plan_windows(int d, const std::vector<uint32_t> &len, std::vector<uint32_t> &window);
 
+template <typename T>
+struct View {                          // borrowed array (pinned host memory owned by the job)
+    const T *p = nullptr;
+    size_t n = 0;
+    const T &operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
+
 struct ExactDeviceResult {             // classes with >= 2 entries, sorted by representative
-    std::vector<uint64_t> cls;         // rep<<32 | start (start unused on the host)
-    std::vector<uint32_t> cls_entries; // entries per class (representative included)
-    std::vector<uint64_t> ent_off;     // first entry of each class
-    std::vector<uint32_t> ent;         // entry positions (global coordinate)
-    std::vector<uint8_t> ent_dir;      // entry directions
-    std::vector<uint8_t> merge_prev;   // class continues the block of the previous class
+    View<uint64_t> cls;                // rep<<32 | start (start unused on the host)
+    View<uint32_t> cls_entries;        // entries per class (representative included)
+    View<uint64_t> ent_off;            // first entry of each class
+    View<uint32_t> ent;                // entry positions (global coordinate)
+    View<uint8_t> ent_dir;             // entry directions
+    View<uint8_t> merge_prev;          // class continues the block of the previous class
 };
 
 struct InexactDeviceResult {           // directed items sorted by (source, target)
-    std::vector<uint64_t> key;         // src<<32 | tgt
-    std::vector<uint32_t> meta;        // kernels.hpp bit layout
-    std::vector<int16_t> blen;         // -1 absorbed, else block length (valid for lists without ties)
-    std::vector<uint32_t> node_start;  // [n_nodes+1]
+    View<uint64_t> key;                // src<<32 | tgt
+    View<uint32_t> meta;               // kernels.hpp bit layout
+    View<int16_t> blen;                // -1 absorbed, else block length (valid for lists without ties)
+    View<uint32_t> node_start;         // [n_nodes+1]
 };
 
 struct FinishStats { uint64_t exact_nodes = 0, inexact_nodes = 0, dirty_nodes = 0, big_nodes = 0; };
 
 void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, std::vector<uint8_t> &out, FinishStats &st);
 // packed: the 2-bit genome (needed only when a list has tied targets); may be empty if none has.
-void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, const std::vector<uint64_t> &packed,
-                       std::vector<uint8_t> &out, FinishStats &st);
+// n_threads host threads each serialise a contiguous range of source positions.
+void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
+                       std::vector<uint8_t> &out, FinishStats &st, int n_threads);
 
 }  // namespace cora

@@ -31,24 +31,95 @@ static int fail(int code, const char *fmt, ...)
 #define HIPQ(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(100, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define RCQ(x) do { int r_ = (x); if (r_) return r_; } while (0)
 
+// Device memory pool of one job: stages allocate and release dozens of arrays per run and
+// hipMalloc/hipFree of large blocks cost milliseconds each (hipFree also synchronises the device),
+// so released blocks are kept and handed out again (same sizes recur every run).
+struct DevPool {
+    struct Block { void *p; size_t bytes; bool free; };
+    std::vector<Block> blocks;
+    void *get(size_t bytes)
+    {
+        bytes = (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
+        int best = -1;
+        for (size_t i = 0; i < blocks.size(); i++)
+            if (blocks[i].free && blocks[i].bytes >= bytes && blocks[i].bytes <= bytes + bytes / 4 + (4u << 20) &&
+                (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = (int)i;
+        if (best >= 0) { blocks[best].free = false; return blocks[best].p; }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            trim();                                          // give cached blocks back and retry once
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        }
+        blocks.push_back({p, bytes, false});
+        return p;
+    }
+    void put(void *p)
+    {
+        for (auto &b : blocks) if (b.p == p) { b.free = true; return; }
+    }
+    void trim()
+    {
+        std::vector<Block> keep;
+        for (auto &b : blocks) { if (b.free) (void)hipFree(b.p); else keep.push_back(b); }
+        blocks.swap(keep);
+    }
+    void destroy()
+    {
+        for (auto &b : blocks) (void)hipFree(b.p);
+        blocks.clear();
+    }
+};
+static thread_local DevPool *g_pool = nullptr;       // pool of the job the calling thread is working for
+
 template <typename T>
 struct DBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevPool *pool = nullptr;
     int alloc(size_t count)
     {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc(&p, count * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; return fail(101, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); }
+        pool = g_pool;
+        if (pool) p = (T *)pool->get(count * sizeof(T));
+        else if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) p = nullptr;
+        if (!p) return fail(101, "device allocation of %zu bytes failed", count * sizeof(T));
         n = count;
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release()
+    {
+        if (p) { if (pool) pool->put(p); else (void)hipFree(p); }
+        p = nullptr; n = 0;
+    }
     ~DBuf() { release(); }
     DBuf() {}
     DBuf(const DBuf &) = delete;
     DBuf &operator=(const DBuf &) = delete;
+};
+
+// grow-only pinned host array for results copied back every run
+template <typename T>
+struct HBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t count)
+    {
+        if (count <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = count + count / 8 + 1024;
+        if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) { p = nullptr; return fail(101, "pinned host allocation of %zu bytes failed", want * sizeof(T)); }
+        cap = want;
+        return 0;
+    }
+    ~HBuf() { if (p) (void)hipHostFree(p); }
+};
+
+struct PoolScope {                                       // binds a job's pool to the calling thread for one API call
+    DevPool *prev;
+    explicit PoolScope(DevPool *p) : prev(g_pool) { g_pool = p; }
+    ~PoolScope() { g_pool = prev; }
 };
 
 struct cora_hip_job {
@@ -67,6 +138,12 @@ struct cora_hip_job {
     DBuf<DevCounters> ctr;
     SortScratch sort_scratch;
     SortTiming sort_timing;
+    DevPool pool;
+    HBuf<u64> h_cls, h_ent_off, h_key, h_packed;
+    HBuf<u32> h_cls_entries, h_ent, h_meta, h_node_start;
+    HBuf<u8> h_ent_dir, h_merge_prev;
+    HBuf<int16_t> h_blen;
+    int host_threads = 8;
     std::vector<uint8_t> exact_bytes, inexact_bytes;
     cora_hip_stats stats;
 };
@@ -120,6 +197,9 @@ extern "C" void cora_hip_job_destroy(cora_hip_job *job)
 {
     if (!job) return;
     job->sort_scratch.release();
+    job->raw.release(); job->d_gstart.release(); job->d_off.release(); job->d_len.release(); job->d_window.release();
+    job->pk.release(); job->bad.release(); job->ctr.release();
+    job->pool.destroy();
     for (auto &e : job->ev) if (e) (void)hipEventDestroy(e);
     if (job->stream) (void)hipStreamDestroy(job->stream);
     delete job;
@@ -210,10 +290,11 @@ static int bits_for(u64 G)
 }
 
 template <typename T>
-static int d2h(cora_hip_job *job, std::vector<T> &dst, const T *src, size_t n)
+static int d2h(cora_hip_job *job, HBuf<T> &dst, View<T> &view, const T *src, size_t n)
 {
-    dst.resize(n);
-    if (n) HIPQ(hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, job->stream));
+    RCQ(dst.reserve(n));
+    if (n) HIPQ(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyDeviceToHost, job->stream));
+    view.p = dst.p; view.n = n;
     return 0;
 }
 
@@ -251,6 +332,7 @@ static int stage_kmers(cora_hip_job *job, DBuf<u64> &hi, DBuf<u64> &lo, DBuf<u32
 extern "C" int cora_hip_job_run(cora_hip_job *job)
 {
     if (!job || !job->have_ref) return fail(51, "no reference set");
+    PoolScope pool_scope(&job->pool);
     const DevParams &dp = job->dp;
     const HostGenome &hg = job->hg;
     hipStream_t s = job->stream;
@@ -292,19 +374,26 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         keys.a = hi.p; keys.b = lo.p; keys.c = gp.p;
         tmp.a = thi.p; tmp.b = tlo.p; tmp.c = tgp.p;
         if (radix_sort(s, keys, tmp, N, 128 - 2 * dp.K, 128, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-        launch_class_count(s, dp, job->pk.p, keys.a, keys.b, keys.c, N, job->ctr.p);
-        DevCounters h;
-        RCQ(read_counters(job, h));
-        NR = h.n_reps;
-        const u64 NNS = h.n_nonsingle;
+        const u32 kb = (u32)((N + 255) / 256);
+        DBuf<u32> blk_reps, blk_nons;
+        DBuf<u64> blk_min, reps_off, nons_off, scr2, tots;
+        RCQ(blk_reps.alloc(kb)); RCQ(blk_nons.alloc(kb)); RCQ(blk_min.alloc(kb)); RCQ(reps_off.alloc(kb)); RCQ(nons_off.alloc(kb));
+        RCQ(scr2.alloc(scan_scratch_elems(kb))); RCQ(tots.alloc(2));
+        launch_class_count(s, dp, job->pk.p, keys.a, keys.b, keys.c, N, blk_reps.p, blk_nons.p, (unsigned long long *)blk_min.p, job->ctr.p);
+        if (exclusive_scan_u32_to_u64(s, blk_reps.p, reps_off.p, kb, scr2.p, tots.p)) return fail(100, "scan launch failed");
+        if (exclusive_scan_u32_to_u64(s, blk_nons.p, nons_off.p, kb, scr2.p, tots.p + 1)) return fail(100, "scan launch failed");
+        u64 totals[2] = {0, 0};
+        HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        NR = totals[0];
+        const u64 NNS = totals[1];
         st.representatives = NR; st.exact_classes = NNS;
         if (NNS >= (1ull << 32)) return fail(19, "too many classes");
-        DBuf<u32> repmask, fill;
+        DBuf<u32> repmask;
         DBuf<u64> cls, cls_tmp;
-        RCQ(repmask.alloc(dp.n_words)); RCQ(fill.alloc(1)); RCQ(cls.alloc(NNS)); RCQ(cls_tmp.alloc(NNS));
+        RCQ(repmask.alloc(dp.n_words)); RCQ(cls.alloc(NNS)); RCQ(cls_tmp.alloc(NNS));
         HIPQ(hipMemsetAsync(repmask.p, 0, dp.n_words * sizeof(u32), s));
-        HIPQ(hipMemsetAsync(fill.p, 0, sizeof(u32), s));
-        launch_class_emit(s, dp, keys.a, keys.b, keys.c, N, repmask.p, cls.p, fill.p);
+        launch_class_emit(s, dp, keys.a, keys.b, keys.c, N, repmask.p, cls.p, nons_off.p);
         // representatives in position order
         {
             const u32 nb = (u32)((dp.n_words + 255) / 256);
@@ -334,12 +423,12 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
             RCQ(ent.alloc(NE)); RCQ(edir.alloc(NE)); RCQ(mp.alloc(NNS));
             launch_class_entries(s, dp, job->pk.p, keys.c, ck.a, (u32)NNS, cm.p, cf.p, eoff.p, ent.p, edir.p);
             launch_class_merge(s, ck.a, (u32)NNS, ce.p, eoff.p, ent.p, edir.p, mp.p);
-            RCQ(d2h(job, er.cls, (const u64 *)ck.a, NNS));
-            RCQ(d2h(job, er.cls_entries, (const u32 *)ce.p, NNS));
-            RCQ(d2h(job, er.ent_off, (const u64 *)eoff.p, NNS));
-            RCQ(d2h(job, er.ent, (const u32 *)ent.p, NE));
-            RCQ(d2h(job, er.ent_dir, (const u8 *)edir.p, NE));
-            RCQ(d2h(job, er.merge_prev, (const u8 *)mp.p, NNS));
+            RCQ(d2h(job, job->h_cls, er.cls, (const u64 *)ck.a, NNS));
+            RCQ(d2h(job, job->h_cls_entries, er.cls_entries, (const u32 *)ce.p, NNS));
+            RCQ(d2h(job, job->h_ent_off, er.ent_off, (const u64 *)eoff.p, NNS));
+            RCQ(d2h(job, job->h_ent, er.ent, (const u32 *)ent.p, NE));
+            RCQ(d2h(job, job->h_ent_dir, er.ent_dir, (const u8 *)edir.p, NE));
+            RCQ(d2h(job, job->h_merge_prev, er.merge_prev, (const u8 *)mp.p, NNS));
             HIPQ(hipStreamSynchronize(s));
         }
         HIPQ(hipGetLastError());
@@ -353,38 +442,40 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
 
     // ---- stage 3: per seed: codes, sort, equal runs, verification (HTS:2671-2800, 2138-2265) ----
     DBuf<PairRec> pairs;
-    u64 pair_cap = NR / 4 + (1u << 20);
+    u64 pair_cap = NR / 8 + (1u << 20);
     u64 n_pairs = 0;
     {
         RCQ(pairs.alloc(pair_cap));
-        DBuf<u64> codes, codes_tmp;
+        DBuf<u64> codes, codes_tmp, blk_off, cand_off, scr, tots;
+        DBuf<u32> blk_recs, blk_cand;
+        const u32 vb = (u32)((NR + 255) / 256);
         RCQ(codes.alloc(NR)); RCQ(codes_tmp.alloc(NR));
-        for (int seed = 1; seed <= dp.nseeds; seed++) {
+        RCQ(blk_recs.alloc(vb)); RCQ(blk_cand.alloc(vb)); RCQ(blk_off.alloc(vb)); RCQ(cand_off.alloc(vb));
+        RCQ(scr.alloc(scan_scratch_elems(vb))); RCQ(tots.alloc(2));
+        for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
             SortArrays ck, ct;
             ck.a = codes.p; ct.a = codes_tmp.p;
             launch_seed_codes(s, dp, job->pk.p, reps.p, NR, seed, ck.a);
             if (radix_sort(s, ck, ct, NR, 32, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-            DevCounters before;
-            RCQ(read_counters(job, before));
-            for (;;) {
-                launch_verify(s, dp, job->pk.p, ck.a, NR, seed, pairs.p, pair_cap, job->ctr.p);
-                DevCounters after;
-                RCQ(read_counters(job, after));
-                if (after.n_pairs <= pair_cap) { n_pairs = after.n_pairs; break; }
-                // grow and redo this seed
-                const u64 want = after.n_pairs + after.n_pairs / 2 + (1u << 20);
+            launch_verify_count(s, dp, job->pk.p, ck.a, NR, seed, blk_recs.p, blk_cand.p);
+            if (exclusive_scan_u32_to_u64(s, blk_recs.p, blk_off.p, vb, scr.p, tots.p)) return fail(100, "scan launch failed");
+            if (exclusive_scan_u32_to_u64(s, blk_cand.p, cand_off.p, vb, scr.p, tots.p + 1)) return fail(100, "scan launch failed");
+            u64 totals[2] = {0, 0};
+            HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
+            HIPQ(hipStreamSynchronize(s));
+            st.candidate_pairs += totals[1];
+            if (n_pairs + totals[0] > pair_cap) {                 // grow, keeping the earlier seeds' records
+                const u64 want = (n_pairs + totals[0]) * 2;
                 DBuf<PairRec> bigger;
                 RCQ(bigger.alloc(want));
-                if (before.n_pairs) HIPQ(hipMemcpyAsync(bigger.p, pairs.p, before.n_pairs * sizeof(PairRec), hipMemcpyDeviceToDevice, s));
+                if (n_pairs) HIPQ(hipMemcpyAsync(bigger.p, pairs.p, n_pairs * sizeof(PairRec), hipMemcpyDeviceToDevice, s));
                 HIPQ(hipStreamSynchronize(s));
                 std::swap(pairs.p, bigger.p); std::swap(pairs.n, bigger.n);
                 pair_cap = want;
-                RCQ(write_counters(job, before));
             }
+            if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, NR, seed, blk_off.p, pairs.p + n_pairs);
+            n_pairs += totals[0];
         }
-        DevCounters h;
-        RCQ(read_counters(job, h));
-        st.candidate_pairs = h.n_candidates;
         st.hom_pairs = n_pairs;
     }
     reps.release();
@@ -393,7 +484,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
 
     // ---- stage 4: directed items, (source,target) sort, lists, diagonal block merge (HTS:1022-1270) ----
     InexactDeviceResult ir;
-    std::vector<u64> packed_host;
+    View<u64> packed_host;
+    static const u32 zero_node = 0;
     const u64 M = 2 * n_pairs;
     if (M >= (1ull << 32)) return fail(19, "too many directed items (%llu)", (unsigned long long)M);
     st.inexact_items = M;
@@ -421,16 +513,16 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         HIPQ(hipMemcpyAsync(nstart.p + n_nodes, &m32, sizeof(u32), hipMemcpyHostToDevice, s));
         launch_chain(s, dp, kk.a, kk.c, hf.p, nexcl.p, nstart.p, (u32)n_nodes, M, blen.p);
         HIPQ(hipGetLastError());
-        RCQ(d2h(job, ir.key, (const u64 *)kk.a, M));
-        RCQ(d2h(job, ir.meta, (const u32 *)kk.c, M));
-        RCQ(d2h(job, ir.blen, (const int16_t *)blen.p, M));
-        RCQ(d2h(job, ir.node_start, (const u32 *)nstart.p, n_nodes + 1));
+        RCQ(d2h(job, job->h_key, ir.key, (const u64 *)kk.a, M));
+        RCQ(d2h(job, job->h_meta, ir.meta, (const u32 *)kk.c, M));
+        RCQ(d2h(job, job->h_blen, ir.blen, (const int16_t *)blen.p, M));
+        RCQ(d2h(job, job->h_node_start, ir.node_start, (const u32 *)nstart.p, n_nodes + 1));
         DevCounters h;
         RCQ(read_counters(job, h));
-        if (h.n_dirty) RCQ(d2h(job, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
+        if (h.n_dirty) RCQ(d2h(job, job->h_packed, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
         HIPQ(hipStreamSynchronize(s));
     } else {
-        ir.node_start.assign(1, 0);
+        ir.node_start.p = &zero_node; ir.node_start.n = 1;
     }
     HIPQ(hipEventRecord(job->ev[4], s));
     HIPQ(hipStreamSynchronize(s));
@@ -438,7 +530,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     // ---- stage 5: final ordering and serialisation on the host (HTS:1353-1432) ----
     {
         const auto h0 = std::chrono::steady_clock::now();
-        serialize_inexact(hg, ir, packed_host, job->inexact_bytes, fst);
+        serialize_inexact(hg, ir, packed_host, job->inexact_bytes, fst, job->host_threads);
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     }
     st.exact_nodes = fst.exact_nodes; st.inexact_nodes = fst.inexact_nodes;
@@ -536,6 +628,7 @@ extern "C" int cora_hip_test_pack(cora_hip_job *job, uint64_t *packed, uint32_t 
 extern "C" int cora_hip_test_kmers(cora_hip_job *job, uint64_t *key_hi, uint64_t *key_lo, uint32_t *gpos, uint64_t cap, uint64_t *n_out)
 {
     if (!job || !job->have_ref) return fail(51, "no reference set");
+    PoolScope pool_scope(&job->pool);
     DBuf<u64> hi, lo;
     DBuf<u32> gp;
     u64 n = 0;

@@ -215,15 +215,21 @@ __device__ __forceinline__ bool key_is_palindrome(int K, u64 hi, u64 lo)
     return rhi == hi && rlo == lo;
 }
 
-// Counts representatives (= classes, HTS:2573-2578), classes with >= 2 entries, and finds the
-// first singleton class in the reference's class-id order (group, position): classes created
-// before it escape the direction flip (Q3, HTS:421-433).
+// Per block of 256 sorted keys: number of representatives (= classes, HTS:2573-2578), number of
+// classes with >= 2 entries, and the smallest (group, position) of a singleton class.  The last one
+// locates the first singleton in the reference's class-id order: classes created before it escape
+// the direction flip (Q3, HTS:421-433).  Per-block partials instead of global counters: same-address
+// atomics cost about 12 ns each chip-wide and there would be one per wave.
 __global__ __launch_bounds__(256) void k_class_count(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ hi,
                                                      const u64 *__restrict__ lo, const u32 *__restrict__ gpos, u64 n,
-                                                     DevCounters *ctr)
+                                                     u32 *__restrict__ blk_reps, u32 *__restrict__ blk_nons,
+                                                     unsigned long long *__restrict__ blk_min)
 {
+    __shared__ u32 s_reps[4], s_nons[4];
+    __shared__ unsigned long long s_min[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     bool head = false, nons = false;
+    unsigned long long key = ~0ull;
     if (i < n) {
         const u64 h = hi[i], l = lo[i];
         head = (i == 0) || hi[i - 1] != h || lo[i - 1] != l;
@@ -231,32 +237,74 @@ __global__ __launch_bounds__(256) void k_class_count(DevParams p, const u64 *__r
             const bool next_head = (i + 1 == n) || hi[i + 1] != h || lo[i + 1] != l;
             if (next_head && !key_is_palindrome(p.K, h, l)) {
                 const u64 g = gpos[i];
-                const unsigned long long key = ((unsigned long long)window_group(p, pk, g) << 32) | g;
-                atomicMin(&ctr->first_singleton_key, key);
+                key = ((unsigned long long)window_group(p, pk, g) << 32) | g;
             } else nons = true;
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o, 64);
+        key = other < key ? other : key;
+    }
     const u64 bh = __ballot(head), bn = __ballot(nons);
-    if ((threadIdx.x & 63) == 0) {
-        if (bh) atomicAdd(&ctr->n_reps, (unsigned long long)__popcll(bh));
-        if (bn) atomicAdd(&ctr->n_nonsingle, (unsigned long long)__popcll(bn));
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_reps[wv] = (u32)__popcll(bh); s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_reps[blockIdx.x] = s_reps[0] + s_reps[1] + s_reps[2] + s_reps[3];
+        blk_nons[blockIdx.x] = s_nons[0] + s_nons[1] + s_nons[2] + s_nons[3];
+        unsigned long long m = s_min[0];
+        for (int w = 1; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;
+        blk_min[blockIdx.x] = m;
     }
 }
 
+__global__ __launch_bounds__(256) void k_min_u64(const unsigned long long *__restrict__ in, u64 n, unsigned long long *out)
+{
+    __shared__ unsigned long long s_min[4];
+    unsigned long long m = ~0ull;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) { const unsigned long long v = in[i]; m = v < m ? v : m; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;
+        if (m != ~0ull) atomicMin(out, m);
+    }
+}
+
+// Marks representatives in the position bitmap and lists the classes with >= 2 entries
+// (rep<<32 | index of the class's first key), in key order, at offsets from the scan of blk_nons.
 __global__ __launch_bounds__(256) void k_class_emit(DevParams p, const u64 *__restrict__ hi, const u64 *__restrict__ lo,
                                                     const u32 *__restrict__ gpos, u64 n, u32 *__restrict__ repmask,
-                                                    u64 *__restrict__ cls, u32 *__restrict__ cls_fill)
+                                                    u64 *__restrict__ cls, const u64 *__restrict__ nons_off)
 {
+    __shared__ u32 s_nons[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u64 h = hi[i], l = lo[i];
-    const bool head = (i == 0) || hi[i - 1] != h || lo[i - 1] != l;
-    if (!head) return;
-    const u32 g = gpos[i];
-    atomicOr(&repmask[g >> 5], 1u << (31 - (g & 31)));
-    const bool next_head = (i + 1 == n) || hi[i + 1] != h || lo[i + 1] != l;
-    if (!(next_head && !key_is_palindrome(p.K, h, l))) {
-        const u32 at = atomicAdd(cls_fill, 1u);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool nons = false;
+    u32 g = 0;
+    if (i < n) {
+        const u64 h = hi[i], l = lo[i];
+        const bool head = (i == 0) || hi[i - 1] != h || lo[i - 1] != l;
+        if (head) {
+            g = gpos[i];
+            atomicOr(&repmask[g >> 5], 1u << (31 - (g & 31)));
+            const bool next_head = (i + 1 == n) || hi[i + 1] != h || lo[i + 1] != l;
+            nons = !(next_head && !key_is_palindrome(p.K, h, l));
+        }
+    }
+    const u64 bn = __ballot(nons);
+    if (lane == 0) s_nons[wv] = (u32)__popcll(bn);
+    __syncthreads();
+    if (nons) {
+        u32 pre = 0;
+        for (int w = 0; w < wv; w++) pre += s_nons[w];
+        const u64 at = nons_off[blockIdx.x] + pre + (u32)__popcll(bn & ((1ull << lane) - 1ull));
         cls[at] = ((u64)g << 32) | (u64)(u32)i;
     }
 }
@@ -407,6 +455,14 @@ __device__ __forceinline__ Mism mism_of(u64 ah, u64 al, u64 bh, u64 bl)
     return m;
 }
 
+// smallest remaining 1-based mismatch offset (0 when none is left); clears it
+__device__ __forceinline__ u32 pop_offset(u64 &eh, u64 &el)
+{
+    if (eh) { const int lz = __clzll((long long)eh); eh &= ~(0x8000000000000000ull >> lz); return (u32)(lz >> 1) + 1u; }
+    if (el) { const int lz = __clzll((long long)el); el &= ~(0x8000000000000000ull >> lz); return 33u + (u32)(lz >> 1); }
+    return 0;
+}
+
 // CompareAndReport (HTS:2138-2265) on one orientation's mismatch mask.  Returns meta or 0xFFFFFFFF.
 __device__ __forceinline__ u32 judge(const DevParams &p, Mism m, int seed, u32 dir)
 {
@@ -415,69 +471,95 @@ __device__ __forceinline__ u32 judge(const DevParams &p, Mism m, int seed, u32 d
     if (nerr == 0 || nerr > p.d) return 0xFFFFFFFFu;
     for (int s = 0; s < seed - 1; s++)                          // reported by the first seed that matches exactly (HTS:2222-2232)
         if (((m.hi & p.seedmask_hi[s]) | (m.lo & p.seedmask_lo[s])) == 0) return 0xFFFFFFFFu;
-    u32 off[3] = {0, 0, 0};
-    int k = 0;
-    u64 t = eh;
-    while (t) { const int lz = __clzll((long long)t); off[k++] = (u32)(lz >> 1) + 1u; t &= ~(0x8000000000000000ull >> lz); }
-    t = el;
-    while (t) { const int lz = __clzll((long long)t); off[k++] = 32u + (u32)(lz >> 1) + 1u; t &= ~(0x8000000000000000ull >> lz); }
-    return meta_pack(dir, off[0], off[1], off[2], (u32)(seed - 1), 0, 0);
-}
-
-__device__ __forceinline__ void emit_pair(PairRec *__restrict__ pairs, u64 cap, DevCounters *ctr, u32 p1, u32 p2, u32 meta)
-{
-    const unsigned long long at = atomicAdd(&ctr->n_pairs, 1ull);
-    if (at < cap) { pairs[at].p1 = p1; pairs[at].p2 = p2; pairs[at].meta = meta; }
+    u64 th = eh, tl = el;
+    const u32 o1 = pop_offset(th, tl), o2 = pop_offset(th, tl), o3 = pop_offset(th, tl);
+    return meta_pack(dir, o1, o2, o3, (u32)(seed - 1), 0, 0);
 }
 
 // One thread per representative in (canonical code, position) order.  It is compared with every
 // EARLIER representative of its equal-code run (HTS:2753-2762: k-mer 1 is the later one).
 // The orientation is the one in which the seed positions agree; a palindromic code agrees in both,
 // and the reference then compares both ways and meets every earlier entry twice (Q1, HTS:2769-2792).
+//
+// Two passes and no atomics (a counter bumped once per wave was 12 ns x 10^6 waves = most of the
+// first profile): WRITE=false counts each block's records and comparisons, the host scans the block
+// counts, WRITE=true repeats the comparisons and stores the records at block offset + rank.  Record
+// order is therefore deterministic: by (code, position) of k-mer 1, then later partners first.
+template <bool WRITE>
 __global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ codes, u64 n_reps,
-                                                int seed, PairRec *__restrict__ pairs, u64 cap, DevCounters *ctr)
+                                                int seed, u32 *__restrict__ blk_recs, u32 *__restrict__ blk_cand,
+                                                const u64 *__restrict__ blk_off, PairRec *__restrict__ pairs)
 {
+    __shared__ u32 l4[4];
+    constexpr u32 INV = 0xFFFFFFFFu;
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_reps) return;
-    const u64 ci = codes[i];
-    const u32 code = (u32)(ci >> 32), gi = (u32)ci;
-    if (i == 0 || (u32)(codes[i - 1] >> 32) != code) {
-        if (rc_code(code) != code) return;                 // run head, nothing earlier to meet
-    }
-    const bool pal = rc_code(code) == code;
-    u64 ih, il;
-    load_window(p, pk, gi, ih, il);
-    const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
-    unsigned long long ncand = 0;
-    if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
-        u64 rh, rl;
-        rc_window(p.K, ih, il, rh, rl);
-        const u32 meta = judge(p, mism_of(ih, il, rh, rl), seed, 1);
-        ncand++;
-        if (meta != 0xFFFFFFFFu) emit_pair(pairs, cap, ctr, gi, gi, meta | (1u << 24));
-    }
-    for (u64 j = i; j-- > 0;) {
-        const u64 cj = codes[j];
-        if ((u32)(cj >> 32) != code) break;
-        const u32 gj = (u32)cj;
-        u64 jh, jl, rh, rl;
-        load_window(p, pk, gj, jh, jl);
-        rc_window(p.K, jh, jl, rh, rl);
-        const Mism same = mism_of(ih, il, jh, jl), rev = mism_of(ih, il, rh, rl);
-        const bool same_ok = ((same.hi & smh) | (same.lo & sml)) == 0;
-        if (pal) {
-            ncand += 4;
-            const u32 m0 = judge(p, same, seed, 0);
-            if (m0 != 0xFFFFFFFFu) { emit_pair(pairs, cap, ctr, gi, gj, m0); emit_pair(pairs, cap, ctr, gi, gj, m0 | (1u << 25)); }
-            const u32 m1 = judge(p, rev, seed, 1);
-            if (m1 != 0xFFFFFFFFu) { emit_pair(pairs, cap, ctr, gi, gj, m1 | (1u << 24)); emit_pair(pairs, cap, ctr, gi, gj, m1 | (1u << 24) | (1u << 25)); }
-        } else {
-            ncand++;
-            const u32 meta = same_ok ? judge(p, same, seed, 0) : judge(p, rev, seed, 1);
-            if (meta != 0xFFFFFFFFu) emit_pair(pairs, cap, ctr, gi, gj, meta);
+    u32 nrec = 0, ncand = 0;
+    u64 at = 0;
+    // in the write pass the records of a thread go to consecutive slots; its first slot needs the
+    // block-wide scan of the counts, so the thread first counts (cheap: candidates are few), then writes
+    for (int pass = WRITE ? 0 : 1; pass < 2; pass++) {
+        const bool store = WRITE && pass == 1;
+        if (pass == 1 && WRITE) {
+            const u32 pre = block_excl_scan_u32(nrec, l4, nullptr);
+            at = blk_off[blockIdx.x] + pre;
+        }
+        if (i < n_reps) {
+            const u64 ci = codes[i];
+            const u32 code = (u32)(ci >> 32), gi = (u32)ci;
+            const bool pal = rc_code(code) == code;
+            const bool run_head = (i == 0) || (u32)(codes[i - 1] >> 32) != code;
+            if (!run_head || pal) {
+                u64 ih, il;
+                load_window(p, pk, gi, ih, il);
+                const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
+                if (pal) {                                  // second pass starts with the k-mer itself (HTS:2781-2787)
+                    u64 rh, rl;
+                    rc_window(p.K, ih, il, rh, rl);
+                    const u32 mr = judge(p, mism_of(ih, il, rh, rl), seed, 1);
+                    if (!store) ncand++;
+                    if (mr != INV) {
+                        if (store) { pairs[at].p1 = gi; pairs[at].p2 = gi; pairs[at].meta = mr | (1u << 24); at++; }
+                        else nrec++;
+                    }
+                }
+                for (u64 j = i; j-- > 0;) {
+                    const u64 cj = codes[j];
+                    if ((u32)(cj >> 32) != code) break;
+                    const u32 gj = (u32)cj;
+                    u64 jh, jl, rh, rl;
+                    load_window(p, pk, gj, jh, jl);
+                    rc_window(p.K, jh, jl, rh, rl);
+                    const Mism same = mism_of(ih, il, jh, jl), rev = mism_of(ih, il, rh, rl);
+                    u32 mf = INV, mr = INV, mr_extra = 0;
+                    if (pal) {
+                        if (!store) ncand += 4;
+                        mf = judge(p, same, seed, 0);
+                        mr = judge(p, rev, seed, 1);
+                        mr_extra = 1u << 24;
+                    } else {
+                        if (!store) ncand++;
+                        const bool same_ok = ((same.hi & smh) | (same.lo & sml)) == 0;
+                        if (same_ok) mf = judge(p, same, seed, 0); else mr = judge(p, rev, seed, 1);
+                    }
+                    const u32 copies = pal ? 2u : 1u;       // palindromic code: every record twice (Q1)
+                    if (mf != INV) {
+                        if (store) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mf | (c << 25); }
+                        else nrec += copies;
+                    }
+                    if (mr != INV) {
+                        if (store) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mr | mr_extra | (c << 25); }
+                        else nrec += copies;
+                    }
+                }
+            }
         }
     }
-    if (ncand) atomicAdd(&ctr->n_candidates, ncand);
+    if (!WRITE) {
+        u32 tr, tc;
+        (void)block_excl_scan_u32(nrec, l4, &tr);
+        (void)block_excl_scan_u32(ncand, l4, &tc);
+        if (threadIdx.x == 0) { blk_recs[blockIdx.x] = tr; blk_cand[blockIdx.x] = tc; }
+    }
 }
 
 // ------------------------------------------------------------------ directed items
@@ -512,7 +594,7 @@ __global__ __launch_bounds__(256) void k_node_flags(const u64 *__restrict__ item
     const u64 k = item_key[i];
     const bool head = (i == 0) || (item_key[i - 1] >> 32) != (k >> 32);
     head_flag[i] = head ? 1u : 0u;
-    if (i > 0 && item_key[i - 1] == k) atomicAdd(&ctr->n_dirty, 1ull);
+    if (i > 0 && item_key[i - 1] == k) ctr->n_dirty = 1;      // any tie: a flag, not a count
 }
 
 __global__ __launch_bounds__(256) void k_node_starts(const u32 *__restrict__ head_flag, const u64 *__restrict__ node_of_excl, u64 m,
@@ -612,14 +694,17 @@ void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_p
     hipLaunchKernelGGL(k_contig_check, grid_for(p.n_contigs), dim3(256), 0, s, p, gpos_by_position, n, ctr);
 }
 void launch_class_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
-                        DevCounters *ctr)
+                        u32 *blk_reps, u32 *blk_nons, unsigned long long *blk_min, DevCounters *ctr)
 {
-    if (n) hipLaunchKernelGGL(k_class_count, grid_for(n), dim3(256), 0, s, p, pk, hi, lo, gpos, n, ctr);
+    if (!n) return;
+    const dim3 g = grid_for(n);
+    hipLaunchKernelGGL(k_class_count, g, dim3(256), 0, s, p, pk, hi, lo, gpos, n, blk_reps, blk_nons, blk_min);
+    hipLaunchKernelGGL(k_min_u64, dim3(g.x < 64 ? g.x : 64), dim3(256), 0, s, blk_min, (u64)g.x, &ctr->first_singleton_key);
 }
 void launch_class_emit(hipStream_t s, const DevParams &p, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n, u32 *repmask,
-                       u64 *cls, u32 *cls_fill)
+                       u64 *cls, const u64 *nons_off)
 {
-    if (n) hipLaunchKernelGGL(k_class_emit, grid_for(n), dim3(256), 0, s, p, hi, lo, gpos, n, repmask, cls, cls_fill);
+    if (n) hipLaunchKernelGGL(k_class_emit, grid_for(n), dim3(256), 0, s, p, hi, lo, gpos, n, repmask, cls, nons_off);
 }
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks)
 {
@@ -648,10 +733,17 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
 {
     if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
 }
-void launch_verify(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed, PairRec *pairs, u64 cap,
-                   DevCounters *ctr)
+void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed, u32 *blk_recs,
+                         u32 *blk_cand)
 {
-    if (n_reps) hipLaunchKernelGGL(k_verify, grid_for(n_reps), dim3(256), 0, s, p, pk, codes, n_reps, seed, pairs, cap, ctr);
+    if (n_reps) hipLaunchKernelGGL((k_verify<false>), grid_for(n_reps), dim3(256), 0, s, p, pk, codes, n_reps, seed, blk_recs, blk_cand,
+                                   (const u64 *)nullptr, (PairRec *)nullptr);
+}
+void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed, const u64 *blk_off,
+                         PairRec *pairs)
+{
+    if (n_reps) hipLaunchKernelGGL((k_verify<true>), grid_for(n_reps), dim3(256), 0, s, p, pk, codes, n_reps, seed, (u32 *)nullptr,
+                                   (u32 *)nullptr, blk_off, pairs);
 }
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta)
 {

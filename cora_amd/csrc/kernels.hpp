@@ -61,9 +61,9 @@ void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u3
                       u32 n_blocks, u64 *key_hi, u64 *key_lo, u32 *gpos);
 void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);
 void launch_class_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
-                        u64 n, DevCounters *ctr);
+                        u64 n, u32 *blk_reps, u32 *blk_nons, unsigned long long *blk_min, DevCounters *ctr);
 void launch_class_emit(hipStream_t s, const DevParams &p, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
-                       u32 *repmask, u64 *cls /* rep<<32|start */, u32 *cls_fill);
+                       u32 *repmask, u64 *cls /* rep<<32|start */, const u64 *nons_off);
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks);
 void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out);
 void launch_class_info(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, u64 n,
@@ -73,8 +73,10 @@ void launch_class_entries(hipStream_t s, const DevParams &p, const u64 *pk, cons
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off,
                         const u32 *ent, const u8 *ent_dir, u8 *merge_prev);
 void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out);
-void launch_verify(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed,
-                   PairRec *pairs, u64 cap, DevCounters *ctr);
+void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed,
+                         u32 *blk_recs, u32 *blk_cand);
+void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed,
+                         const u64 *blk_off, PairRec *pairs);
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta);
 void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr);
 void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start);

@@ -71,6 +71,29 @@ def write_fasta(path: str, contigs, width: int = 60) -> None:
             f.write("%s\t%d\t%d\t%d\t%d\n" % row)
 
 
+def fasta_image(contigs, width: int = 60):
+    """In-memory FASTA file image: -> (uint8 array, line width, [(offset of first base, length)])."""
+    parts, geom, off = [], [], 0
+    for name, seq in contigs:
+        hdr = np.frombuffer(b">" + name.encode() + b"\n", dtype=np.uint8)
+        parts.append(hdr)
+        off += len(hdr)
+        n = len(seq)
+        geom.append((off, n))
+        full = n // width
+        if full:
+            body = np.empty((full, width + 1), dtype=np.uint8)
+            body[:, :width] = seq[: full * width].reshape(full, width)
+            body[:, width] = 10
+            parts.append(body.reshape(-1))
+        rest = n - full * width
+        if rest:
+            parts.append(seq[full * width:])
+            parts.append(np.array([10], dtype=np.uint8))
+        off += n + full + (1 if rest else 0)
+    return np.concatenate(parts), width, geom
+
+
 # --------------------------------------------------------------------------
 # split files (what cora.cpp:295-314 hands to homTable_setup as argv[3]/argv[6])
 # --------------------------------------------------------------------------
