@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 #include <tuple>
@@ -68,25 +69,35 @@ void plan_windows(int d, const std::vector<uint32_t> &len, std::vector<uint32_t>
     }
 }
 
+void ByteBuf::reserve_uninit(size_t c)
+{
+    if (c <= cap) return;
+    free(p);
+    p = (uint8_t *)malloc(c ? c : 1);
+    cap = p ? c : 0;
+}
+ByteBuf::~ByteBuf() { free(p); }
+
 namespace {
 
-struct Writer {
-    std::vector<uint8_t> &v;
+struct Writer {                                           // raw cursor into a buffer sized for the worst case
+    uint8_t *at;
     int cw;                                               // contig id width: 1 or 2 bytes (HTS:210-214)
-    void u8(uint32_t x) { v.push_back((uint8_t)x); }
-    void chr(uint32_t c) { v.push_back((uint8_t)c); if (cw == 2) v.push_back((uint8_t)(c >> 8)); }
-    void u32(uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i))); }
-    void i16(int x) { v.push_back((uint8_t)x); v.push_back((uint8_t)((unsigned)x >> 8)); }
+    void u8(uint32_t x) { *at++ = (uint8_t)x; }
+    void chr(uint32_t c) { *at++ = (uint8_t)c; if (cw == 2) *at++ = (uint8_t)(c >> 8); }
+    void u32(uint32_t x) { memcpy(at, &x, 4); at += 4; }  // little-endian host, as the reference's fwrite
+    void i16(int x) { const int16_t v = (int16_t)x; memcpy(at, &v, 2); at += 2; }
 };
 
 }  // namespace
 
 // F1 (HTS:572-635): rep chr,pos  { dir chr pos }*  0xFF  blockSize; only a block's first class is written.
-void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, std::vector<uint8_t> &out, FinishStats &st)
+void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, ByteBuf &out, FinishStats &st)
 {
-    out.clear();
-    Writer w{out, g.chr_short ? 2 : 1};
     const size_t n = r.cls.size();
+    const int cw = g.chr_short ? 2 : 1;
+    out.reserve_uninit(r.ent.size() * (size_t)(1 + cw + 4) + n * 5 + 16);
+    Writer w{out.p, cw};
     st.exact_nodes = 0;
     for (size_t c = 0; c < n;) {
         size_t e = c + 1;
@@ -105,6 +116,7 @@ void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, std::vecto
         st.exact_nodes++;
         c = e;
     }
+    out.n = (size_t)(w.at - out.p);
 }
 
 namespace {
@@ -154,10 +166,12 @@ void emit_item(Writer &w, const HostGenome &g, int d, uint32_t tgt, uint32_t dir
 // items by decreasing block length through std::sort (HTS:1368; unstable above 16 items, which is why the
 // very same library routine is applied to the very same pre-order here).
 static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResult &r, const View<uint64_t> &packed,
-                                    size_t node_begin, size_t node_end, std::vector<uint8_t> &out, FinishStats &st)
+                                    size_t node_begin, size_t node_end, ByteBuf &out, FinishStats &st)
 {
-    out.clear();
-    Writer w{out, g.chr_short ? 2 : 1};
+    const int cw = g.chr_short ? 2 : 1;
+    const size_t n_items = (size_t)r.node_start[node_end] - r.node_start[node_begin];
+    out.reserve_uninit(n_items * (size_t)(1 + cw + 4 + g.d + 2) + (node_end - node_begin) * (size_t)(cw + 5) + 16);
+    Writer w{out.p, cw};
     st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
     const size_t n_nodes = node_end;
     auto src_of = [&](size_t nd) { return (uint32_t)(r.key[r.node_start[nd]] >> 32); };
@@ -184,6 +198,15 @@ static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResu
         if (!dirty) {
             for (size_t nd = i; nd < j; nd++) {
                 const uint32_t a = r.node_start[nd], b = r.node_start[nd + 1];
+                if (b - a == 1) {                                    // the common case: one item, nothing to order
+                    if (r.blen[a] != -1) {
+                        const uint32_t sp = src_of(nd), m = r.meta[a];
+                        w.chr(ci + 1); w.u32((uint32_t)(sp - g.gstart[ci]) + 1);
+                        emit_item(w, g, g.d, (uint32_t)r.key[a], m & 1u, meta_o1(m), meta_o2(m), meta_o3(m), r.blen[a]);
+                        w.u8(0xFF); st.inexact_nodes++;
+                    }
+                    continue;
+                }
                 order.clear();
                 for (uint32_t k = a; k < b; k++) order.emplace_back(r.blen[k], k);
                 if (b - a > 16) st.big_nodes++;
@@ -260,14 +283,15 @@ static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResu
         }
         i = j;
     }
+    out.n = (size_t)(w.at - out.p);
 }
 
 void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
-                       std::vector<uint8_t> &out, FinishStats &st, int n_threads)
+                       ByteBuf &out, FinishStats &st, int n_threads)
 {
     const size_t n_nodes = r.node_start.empty() ? 0 : r.node_start.size() - 1;
     st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
-    out.clear();
+    out.n = 0;
     if (n_nodes == 0) return;
     auto src_of = [&](size_t nd) { return (uint32_t)(r.key[r.node_start[nd]] >> 32); };
     // a thread's range must start where a run of consecutive source positions starts (runs never
@@ -291,22 +315,25 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
     }
     cut.push_back(n_nodes);
     const size_t parts = cut.size() - 1;
-    std::vector<std::vector<uint8_t>> bufs(parts);
+    std::vector<ByteBuf> bufs(parts);
     std::vector<FinishStats> sts(parts);
     std::vector<std::thread> th;
     for (size_t k = 1; k < parts; k++)
         th.emplace_back([&, k]() { serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k]); });
     serialize_inexact_range(g, r, packed, cut[0], cut[1], bufs[0], sts[0]);
     for (auto &x : th) x.join();
-    size_t total = 0;
-    for (auto &b : bufs) total += b.size();
-    out.resize(total);
-    size_t at = 0;
+    std::vector<size_t> off(parts + 1, 0);
     for (size_t k = 0; k < parts; k++) {
-        if (!bufs[k].empty()) memcpy(out.data() + at, bufs[k].data(), bufs[k].size());
-        at += bufs[k].size();
+        off[k + 1] = off[k] + bufs[k].size();
         st.inexact_nodes += sts[k].inexact_nodes; st.dirty_nodes += sts[k].dirty_nodes; st.big_nodes += sts[k].big_nodes;
     }
+    out.reserve_uninit(off[parts] + 16);
+    out.n = off[parts];
+    th.clear();
+    for (size_t k = 1; k < parts; k++)
+        th.emplace_back([&, k]() { if (bufs[k].size()) memcpy(out.p + off[k], bufs[k].data(), bufs[k].size()); });
+    if (bufs[0].size()) memcpy(out.p, bufs[0].data(), bufs[0].size());
+    for (auto &x : th) x.join();
 }
 
 }  // namespace cora

@@ -53,12 +53,25 @@ struct InexactDeviceResult {           // directed items sorted by (source, targ
     View<uint32_t> node_start;         // [n_nodes+1]
 };
 
+// Uninitialised, grow-only byte buffer (std::vector would zero-fill hundreds of MB per run).
+struct ByteBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    void reserve_uninit(size_t c);
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    ~ByteBuf();
+    ByteBuf() {}
+    ByteBuf(const ByteBuf &) = delete;
+    ByteBuf &operator=(const ByteBuf &) = delete;
+};
+
 struct FinishStats { uint64_t exact_nodes = 0, inexact_nodes = 0, dirty_nodes = 0, big_nodes = 0; };
 
-void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, std::vector<uint8_t> &out, FinishStats &st);
+void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, ByteBuf &out, FinishStats &st);
 // packed: the 2-bit genome (needed only when a list has tied targets); may be empty if none has.
 // n_threads host threads each serialise a contiguous range of source positions.
 void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
-                       std::vector<uint8_t> &out, FinishStats &st, int n_threads);
+                       ByteBuf &out, FinishStats &st, int n_threads);
 
 }  // namespace cora

@@ -144,7 +144,7 @@ struct cora_hip_job {
     HBuf<u8> h_ent_dir, h_merge_prev;
     HBuf<int16_t> h_blen;
     int host_threads = 8;
-    std::vector<uint8_t> exact_bytes, inexact_bytes;
+    ByteBuf exact_bytes, inexact_bytes;
     cora_hip_stats stats;
 };
 
