@@ -8,6 +8,7 @@
 #include <chrono>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -144,6 +145,7 @@ struct cora_hip_job {
     HBuf<u8> h_ent_dir, h_merge_prev;
     HBuf<int16_t> h_blen;
     int host_threads = 8;
+    int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
     ByteBuf exact_bytes, inexact_bytes;
     cora_hip_stats stats;
 };
@@ -187,6 +189,8 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
     memcpy(hg.sig2, params->sig2, 16);
     memcpy(hg.sig4, params->sig4, 256);
     make_seed_template(hg.K, hg.d, hg.tmpl, &hg.seed_q);
+    if (const char *e = getenv("CORA_HASH_BITS")) { int v = atoi(e); if (v >= 8 && v <= 56) j->hash_bits = v & ~7; }
+    if (const char *e = getenv("CORA_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) j->host_threads = v; }
     if (hipStreamCreate(&j->stream) != hipSuccess) { delete j; return fail(100, "hipStreamCreate failed"); }
     for (auto &e : j->ev) if (hipEventCreate(&e) != hipSuccess) { delete j; return fail(100, "hipEventCreate failed"); }
     *out = j;
@@ -298,8 +302,8 @@ static int d2h(cora_hip_job *job, HBuf<T> &dst, View<T> &view, const T *src, siz
     return 0;
 }
 
-// pack + valid windows + canonical keys, in position order
-static int stage_kmers(cora_hip_job *job, DBuf<u64> &hi, DBuf<u64> &lo, DBuf<u32> &gp, u64 &n_kmers, bool alloc_only_exact)
+// pack + valid windows in position order; hashed: 12-byte records (hash|flags, gpos), else full 128-bit keys
+static int stage_kmers(cora_hip_job *job, bool hashed, DBuf<u64> &a, DBuf<u64> &b, DBuf<u32> &gp, u64 &n_kmers)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
@@ -322,9 +326,9 @@ static int stage_kmers(cora_hip_job *job, DBuf<u64> &hi, DBuf<u64> &lo, DBuf<u32
         return fail(51, "FASTA image does not have the fixed line width the reference's loader assumes (%llu misplaced line ends)",
                     (unsigned long long)h.format_errors);
     n_kmers = n;
-    (void)alloc_only_exact;
-    RCQ(hi.alloc(n)); RCQ(lo.alloc(n)); RCQ(gp.alloc(n));
-    launch_kmer_emit(s, dp, job->pk.p, job->bad.p, boff.p, n_blocks, hi.p, lo.p, gp.p);
+    RCQ(a.alloc(n)); RCQ(gp.alloc(n));
+    if (hashed) launch_kmer_emit_hashed(s, dp, job->pk.p, job->bad.p, boff.p, n_blocks, a.p, gp.p);
+    else { RCQ(b.alloc(n)); launch_kmer_emit(s, dp, job->pk.p, job->bad.p, boff.p, n_blocks, a.p, b.p, gp.p); }
     HIPQ(hipStreamSynchronize(s));
     return 0;
 }
@@ -345,11 +349,11 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     double host_ms = 0;
     HIPQ(hipEventRecord(job->ev[0], s));
 
-    // ---- stage 1: pack, keys (HTS:2499-2565) ----
-    DBuf<u64> hi, lo;
+    // ---- stage 1: pack, hashed K-mer records (HTS:2499-2565) ----
+    DBuf<u64> rec, klo;
     DBuf<u32> gp;
     u64 N = 0;
-    RCQ(stage_kmers(job, hi, lo, gp, N, true));
+    RCQ(stage_kmers(job, true, rec, klo, gp, N));
     st.kmers = N;
     HIPQ(hipEventRecord(job->ev[1], s));
     // every contig must own at least one window (else the reference reads before its buffer, HTS:2530)
@@ -366,34 +370,81 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     DBuf<u32> reps;
     u64 NR = 0;
     FinishStats fst;
+    if (N >= (1ull << 32) - 1) return fail(19, "too many K-mers for 32-bit indices");
     {
-        DBuf<u64> thi, tlo;
-        DBuf<u32> tgp;
-        RCQ(thi.alloc(N)); RCQ(tlo.alloc(N)); RCQ(tgp.alloc(N));
+        DBuf<u64> trec, thi, tlo;
+        DBuf<u32> tgp, head_flag, mixed_list;
+        const u32 mixed_cap = 4096;
+        RCQ(trec.alloc(N)); RCQ(tgp.alloc(N)); RCQ(head_flag.alloc(N)); RCQ(mixed_list.alloc(mixed_cap));
+        // Equal canonical keys have equal hashes: sort 12-byte (hash, position) records on the top hb hash bits
+        // (6-7 passes) instead of 20-byte full keys on 2K bits (13 passes); collisions are found and repaired below.
+        int hb = job->hash_bits ? job->hash_bits : (N <= (1ull << 27) ? 48 : 56);
         SortArrays keys, tmp;
-        keys.a = hi.p; keys.b = lo.p; keys.c = gp.p;
-        tmp.a = thi.p; tmp.b = tlo.p; tmp.c = tgp.p;
-        if (radix_sort(s, keys, tmp, N, 128 - 2 * dp.K, 128, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-        const u32 kb = (u32)((N + 255) / 256);
-        DBuf<u32> blk_reps, blk_nons;
-        DBuf<u64> blk_min, reps_off, nons_off, scr2, tots;
-        RCQ(blk_reps.alloc(kb)); RCQ(blk_nons.alloc(kb)); RCQ(blk_min.alloc(kb)); RCQ(reps_off.alloc(kb)); RCQ(nons_off.alloc(kb));
-        RCQ(scr2.alloc(scan_scratch_elems(kb))); RCQ(tots.alloc(2));
-        launch_class_count(s, dp, job->pk.p, keys.a, keys.b, keys.c, N, blk_reps.p, blk_nons.p, (unsigned long long *)blk_min.p, job->ctr.p);
-        if (exclusive_scan_u32_to_u64(s, blk_reps.p, reps_off.p, kb, scr2.p, tots.p)) return fail(100, "scan launch failed");
-        if (exclusive_scan_u32_to_u64(s, blk_nons.p, nons_off.p, kb, scr2.p, tots.p + 1)) return fail(100, "scan launch failed");
-        u64 totals[2] = {0, 0};
-        HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
+        keys.a = rec.p; keys.c = gp.p; tmp.a = trec.p; tmp.c = tgp.p;
+        if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+        launch_same_detect(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, mixed_cap, job->ctr.p);
+        DevCounters h;
+        RCQ(read_counters(job, h));
+        bool fallback = false;
+        st.hash_mixed_runs = h.n_mixed;
+        if (h.n_mixed > mixed_cap) fallback = true;
+        else if (h.n_mixed) {
+            launch_mixed_fix(s, dp, job->pk.p, keys.a, keys.c, N, hb, mixed_list.p, (u32)h.n_mixed, job->ctr.p);
+            DevCounters z = h;
+            z.n_mixed = 0;
+            RCQ(read_counters(job, h));
+            z.fallback = h.fallback;
+            RCQ(write_counters(job, z));
+            launch_same_detect(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, mixed_cap, job->ctr.p);
+            RCQ(read_counters(job, h));
+            if (h.n_mixed || h.fallback) fallback = true;
+        }
+        const u64 *rec_sorted = keys.a;
+        const u32 *gp_sorted = keys.c;
+        DBuf<u64> fhi, flo;
+        DBuf<u32> fgp;
+        if (fallback) {                 // a long run of colliding keys: redo with the full 128-bit keys (always exact)
+            st.full_key_fallback = 1;
+            u64 N2 = 0;
+            RCQ(stage_kmers(job, false, fhi, flo, fgp, N2));
+            if (N2 != N) return fail(100, "internal: window count changed");
+            RCQ(thi.alloc(N)); RCQ(tlo.alloc(N));
+            SortArrays fk, ft;
+            fk.a = fhi.p; fk.b = flo.p; fk.c = fgp.p; ft.a = thi.p; ft.b = tlo.p; ft.c = tgp.p;
+            if (radix_sort(s, fk, ft, N, 128 - 2 * dp.K, 128, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+            launch_heads_from_keys(s, dp, job->pk.p, fk.a, fk.b, fk.c, N, head_flag.p, rec.p);
+            if (fk.c != fgp.p) HIPQ(hipMemcpyAsync(fgp.p, fk.c, N * sizeof(u32), hipMemcpyDeviceToDevice, s));
+            rec_sorted = rec.p; gp_sorted = fgp.p;
+        }
+        // class index of every record, class starts
+        DBuf<u64> cid, scr0, tot0;
+        RCQ(cid.alloc(N)); RCQ(scr0.alloc(scan_scratch_elems(N))); RCQ(tot0.alloc(1));
+        if (exclusive_scan_u32_to_u64(s, head_flag.p, cid.p, N, scr0.p, tot0.p)) return fail(100, "scan launch failed");
+        HIPQ(hipMemcpyAsync(&NR, tot0.p, sizeof NR, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
-        NR = totals[0];
-        const u64 NNS = totals[1];
+        DBuf<u32> class_start;
+        RCQ(class_start.alloc(NR + 1));
+        launch_node_starts(s, head_flag.p, cid.p, N, class_start.p);
+        const u32 n32 = (u32)N;
+        HIPQ(hipMemcpyAsync(class_start.p + NR, &n32, sizeof(u32), hipMemcpyHostToDevice, s));
+        cid.release(); scr0.release();
+
+        const u32 kb = (u32)((NR + 255) / 256);
+        DBuf<u32> blk_nons;
+        DBuf<u64> blk_min, nons_off, scr2, tots;
+        RCQ(blk_nons.alloc(kb)); RCQ(blk_min.alloc(kb)); RCQ(nons_off.alloc(kb));
+        RCQ(scr2.alloc(scan_scratch_elems(kb))); RCQ(tots.alloc(1));
+        launch_class_count(s, rec_sorted, gp_sorted, class_start.p, (u32)NR, blk_nons.p, (unsigned long long *)blk_min.p, job->ctr.p);
+        if (exclusive_scan_u32_to_u64(s, blk_nons.p, nons_off.p, kb, scr2.p, tots.p)) return fail(100, "scan launch failed");
+        u64 NNS = 0;
+        HIPQ(hipMemcpyAsync(&NNS, tots.p, sizeof NNS, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
         st.representatives = NR; st.exact_classes = NNS;
-        if (NNS >= (1ull << 32)) return fail(19, "too many classes");
         DBuf<u32> repmask;
         DBuf<u64> cls, cls_tmp;
         RCQ(repmask.alloc(dp.n_words)); RCQ(cls.alloc(NNS)); RCQ(cls_tmp.alloc(NNS));
         HIPQ(hipMemsetAsync(repmask.p, 0, dp.n_words * sizeof(u32), s));
-        launch_class_emit(s, dp, keys.a, keys.b, keys.c, N, repmask.p, cls.p, nons_off.p);
+        launch_class_emit(s, rec_sorted, gp_sorted, class_start.p, (u32)NR, repmask.p, cls.p, nons_off.p);
         // representatives in position order
         {
             const u32 nb = (u32)((dp.n_words + 255) / 256);
@@ -411,17 +462,17 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
             SortArrays ck, ct;
             ck.a = cls.p; ct.a = cls_tmp.p;
             if (radix_sort(s, ck, ct, NNS, 32, 32 + bits_for(dp.G), job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-            DBuf<u32> cm, cf, ce;
+            DBuf<u32> cf, ce;
             DBuf<u64> eoff, scr, tot;
-            RCQ(cm.alloc(NNS)); RCQ(cf.alloc(NNS)); RCQ(ce.alloc(NNS)); RCQ(eoff.alloc(NNS)); RCQ(scr.alloc(scan_scratch_elems(NNS))); RCQ(tot.alloc(1));
-            launch_class_info(s, dp, job->pk.p, keys.a, keys.b, N, ck.a, (u32)NNS, job->ctr.p, cm.p, cf.p, ce.p);
+            RCQ(cf.alloc(NNS)); RCQ(ce.alloc(NNS)); RCQ(eoff.alloc(NNS)); RCQ(scr.alloc(scan_scratch_elems(NNS))); RCQ(tot.alloc(1));
+            launch_class_info(s, rec_sorted, class_start.p, ck.a, (u32)NNS, job->ctr.p, cf.p, ce.p);
             if (exclusive_scan_u32_to_u64(s, ce.p, eoff.p, NNS, scr.p, tot.p)) return fail(100, "scan launch failed");
             u64 NE = 0;
             HIPQ(hipMemcpyAsync(&NE, tot.p, sizeof NE, hipMemcpyDeviceToHost, s));
             HIPQ(hipStreamSynchronize(s));
             DBuf<u32> ent; DBuf<u8> edir, mp;
             RCQ(ent.alloc(NE)); RCQ(edir.alloc(NE)); RCQ(mp.alloc(NNS));
-            launch_class_entries(s, dp, job->pk.p, keys.c, ck.a, (u32)NNS, cm.p, cf.p, eoff.p, ent.p, edir.p);
+            launch_class_entries(s, rec_sorted, gp_sorted, class_start.p, ck.a, (u32)NNS, cf.p, eoff.p, ent.p, edir.p);
             launch_class_merge(s, ck.a, (u32)NNS, ce.p, eoff.p, ent.p, edir.p, mp.p);
             RCQ(d2h(job, job->h_cls, er.cls, (const u64 *)ck.a, NNS));
             RCQ(d2h(job, job->h_cls_entries, er.cls_entries, (const u32 *)ce.p, NNS));
@@ -438,7 +489,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         serialize_exact(hg, er, job->exact_bytes, fst);
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     }
-    hi.release(); lo.release(); gp.release();
+    rec.release(); klo.release(); gp.release();
 
     // ---- stage 3: per seed: codes, sort, equal runs, verification (HTS:2671-2800, 2138-2265) ----
     DBuf<PairRec> pairs;
@@ -632,7 +683,7 @@ extern "C" int cora_hip_test_kmers(cora_hip_job *job, uint64_t *key_hi, uint64_t
     DBuf<u64> hi, lo;
     DBuf<u32> gp;
     u64 n = 0;
-    RCQ(stage_kmers(job, hi, lo, gp, n, true));
+    RCQ(stage_kmers(job, false, hi, lo, gp, n));
     if (n_out) *n_out = n;
     if (n > cap) return fail(19, "buffer too small: %llu windows", (unsigned long long)n);
     HIPQ(hipMemcpy(key_hi, hi.p, n * sizeof(u64), hipMemcpyDeviceToHost));

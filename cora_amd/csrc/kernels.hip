@@ -185,6 +185,128 @@ __global__ __launch_bounds__(256) void k_kmer_emit(DevParams p, const u64 *__res
     gpos[at] = (u32)g;
 }
 
+// Record flags carried in the low 8 bits of a sort record (the hash occupies the bits above):
+//   bit 0 strand (canonical form is the reverse complement, HTS:2563), bit 1 palindrome (fw == rc),
+//   bits 2-5 physical group of the window's (first,last) base pair (HTS:2549).
+__device__ __forceinline__ u32 kmer_flags(const DevParams &p, u64 hi, u64 lo, u64 rhi, u64 rlo)
+{
+    const bool use_rc = (rhi < hi) || (rhi == hi && rlo < lo);
+    const bool pal = (rhi == hi) && (rlo == lo);
+    const u32 grp = p.sig2[base_at(hi, lo, 0) * 4 + base_at(hi, lo, p.K - 1)];
+    return (use_rc ? 1u : 0u) | (pal ? 2u : 0u) | (grp << 2);
+}
+
+__device__ __forceinline__ u64 key_hash(u64 hi, u64 lo)
+{
+    u64 h = hi * 0x9E3779B97F4A7C15ull ^ ((lo << 29) | (lo >> 35)) * 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+    return h;
+}
+
+__device__ __forceinline__ void canonical_at(const DevParams &p, const u64 *__restrict__ pk, u64 g, u64 &chi, u64 &clo)
+{
+    u64 hi, lo, rhi, rlo;
+    load_window(p, pk, g, hi, lo);
+    rc_window(p.K, hi, lo, rhi, rlo);
+    const bool use_rc = (rhi < hi) || (rhi == hi && rlo < lo);
+    chi = use_rc ? rhi : hi; clo = use_rc ? rlo : lo;
+}
+
+// Hashed record of every valid window: rec = (hash of the canonical key & ~0xFF) | flags, plus gpos.
+// Sorting 12-byte records on the top 48/56 hash bits replaces the 13-pass sort of 20-byte full keys;
+// equal keys have equal hashes, and k_same_detect / k_mixed_fix make the grouping exact.
+__global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ bad,
+                                                          const u64 *__restrict__ block_off, u64 *__restrict__ rec,
+                                                          u32 *__restrict__ gpos)
+{
+    __shared__ u32 wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = (g < p.G) && window_ok(p, bad, g);
+    const u64 bal = __ballot(ok);
+    if (lane == 0) wsum[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    if (!ok) return;
+    u32 pre = 0;
+    for (int w = 0; w < wv; w++) pre += wsum[w];
+    const u64 at = block_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+    u64 hi, lo, rhi, rlo;
+    load_window(p, pk, g, hi, lo);
+    rc_window(p.K, hi, lo, rhi, rlo);
+    const u32 fl = kmer_flags(p, hi, lo, rhi, rlo);
+    const u64 h = (fl & 1u) ? key_hash(rhi, rlo) : key_hash(hi, lo);
+    rec[at] = (h & ~0xFFull) | fl;
+    gpos[at] = (u32)g;
+}
+
+// After the sort on the top `hb` hash bits: head_flag[i] = 1 when record i opens a class.  Records with
+// equal truncated hashes have their canonical keys re-read from the packed genome and compared; a key
+// SMALLER than its predecessor's inside an equal-hash run means two different keys collided and are not
+// grouped yet: such positions are listed for k_mixed_fix.
+__global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ rec,
+                                                     const u32 *__restrict__ gpos, u64 n, int hb, u32 *__restrict__ head_flag,
+                                                     u32 *__restrict__ mixed_list, u32 mixed_cap, DevCounters *ctr)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32 head = 1;
+    if (i > 0 && (rec[i] >> (64 - hb)) == (rec[i - 1] >> (64 - hb))) {
+        u64 ah, al, bh, bl;
+        canonical_at(p, pk, gpos[i - 1], ah, al);
+        canonical_at(p, pk, gpos[i], bh, bl);
+        if (ah == bh && al == bl) head = 0;
+        else if (bh < ah || (bh == ah && bl < al)) {
+            const unsigned long long at = atomicAdd(&ctr->n_mixed, 1ull);      // rare: hash collisions only
+            if (at < mixed_cap) mixed_list[at] = (u32)i;
+        }
+    }
+    head_flag[i] = head;
+}
+
+// One thread per listed position: the lowest listed position of an equal-hash run sorts that run by
+// canonical key (stable, so equal keys stay in position order).  Runs longer than 64 records set the
+// fallback flag: the caller then redoes the stage with the full-key sort.
+__global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__restrict__ pk, u64 *__restrict__ rec,
+                                                  u32 *__restrict__ gpos, u64 n, int hb, const u32 *__restrict__ mixed_list,
+                                                  u32 n_mixed, DevCounters *ctr)
+{
+    const u32 t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n_mixed) return;
+    const u64 i = mixed_list[t];
+    const u64 tr = rec[i] >> (64 - hb);
+    u64 s = i, e = i + 1;
+    while (s > 0 && (rec[s - 1] >> (64 - hb)) == tr) { s--; if (i - s > 64) { ctr->fallback = 1; return; } }
+    while (e < n && (rec[e] >> (64 - hb)) == tr) { e++; if (e - s > 64) { ctr->fallback = 1; return; } }
+    for (u32 k = 0; k < n_mixed; k++) { const u64 o = mixed_list[k]; if (o >= s && o < i) return; }   // not the run's first
+    const int L = (int)(e - s);
+    u64 r_[64], kh[64], kl[64];
+    u32 g_[64];
+    for (int k = 0; k < L; k++) { r_[k] = rec[s + k]; g_[k] = gpos[s + k]; canonical_at(p, pk, g_[k], kh[k], kl[k]); }
+    for (int a = 1; a < L; a++) {                         // insertion sort: stable
+        const u64 r0 = r_[a], h0 = kh[a], l0 = kl[a];
+        const u32 g0 = g_[a];
+        int b = a - 1;
+        while (b >= 0 && (kh[b] > h0 || (kh[b] == h0 && kl[b] > l0))) { r_[b + 1] = r_[b]; g_[b + 1] = g_[b]; kh[b + 1] = kh[b]; kl[b + 1] = kl[b]; b--; }
+        r_[b + 1] = r0; g_[b + 1] = g0; kh[b + 1] = h0; kl[b + 1] = l0;
+    }
+    for (int k = 0; k < L; k++) { rec[s + k] = r_[k]; gpos[s + k] = g_[k]; }
+}
+
+// Full-key path (used when k_mixed_fix gives up): class heads from the sorted 128-bit keys, and the
+// flag byte rebuilt from the genome.
+__global__ __launch_bounds__(256) void k_heads_from_keys(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ hi,
+                                                         const u64 *__restrict__ lo, const u32 *__restrict__ gpos, u64 n,
+                                                         u32 *__restrict__ head_flag, u64 *__restrict__ rec)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    head_flag[i] = ((i == 0) || hi[i - 1] != hi[i] || lo[i - 1] != lo[i]) ? 1u : 0u;
+    u64 fh, fl, rh, rl;
+    load_window(p, pk, gpos[i], fh, fl);
+    rc_window(p.K, fh, fl, rh, rl);
+    rec[i] = kmer_flags(p, fh, fl, rh, rl);
+}
+
 // a contig without any window makes the reference read before its buffer (HTS:2530): count them
 __global__ __launch_bounds__(256) void k_contig_check(DevParams p, const u32 *__restrict__ gpos, u64 n, DevCounters *ctr)
 {
@@ -215,43 +337,36 @@ __device__ __forceinline__ bool key_is_palindrome(int K, u64 hi, u64 lo)
     return rhi == hi && rlo == lo;
 }
 
-// Per block of 256 sorted keys: number of representatives (= classes, HTS:2573-2578), number of
-// classes with >= 2 entries, and the smallest (group, position) of a singleton class.  The last one
-// locates the first singleton in the reference's class-id order: classes created before it escape
-// the direction flip (Q3, HTS:421-433).  Per-block partials instead of global counters: same-address
-// atomics cost about 12 ns each chip-wide and there would be one per wave.
-__global__ __launch_bounds__(256) void k_class_count(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ hi,
-                                                     const u64 *__restrict__ lo, const u32 *__restrict__ gpos, u64 n,
-                                                     u32 *__restrict__ blk_reps, u32 *__restrict__ blk_nons,
-                                                     unsigned long long *__restrict__ blk_min)
+// One thread per class (class_start from the scan of the head flags).  Per block of 256 classes: the
+// number of classes with >= 2 entries (>= 2 occurrences, or a palindrome: Q2) and the smallest
+// (group, position) of a singleton class.  The latter locates the first singleton in the reference's
+// class-id order: classes created before it escape the direction flip (Q3, HTS:421-433).  Per-block
+// partials instead of global counters: same-address atomics cost about 12 ns each chip-wide.
+__global__ __launch_bounds__(256) void k_class_count(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
+                                                     const u32 *__restrict__ class_start, u32 n_cls,
+                                                     u32 *__restrict__ blk_nons, unsigned long long *__restrict__ blk_min)
 {
-    __shared__ u32 s_reps[4], s_nons[4];
+    __shared__ u32 s_nons[4];
     __shared__ unsigned long long s_min[4];
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    bool head = false, nons = false;
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    bool nons = false;
     unsigned long long key = ~0ull;
-    if (i < n) {
-        const u64 h = hi[i], l = lo[i];
-        head = (i == 0) || hi[i - 1] != h || lo[i - 1] != l;
-        if (head) {
-            const bool next_head = (i + 1 == n) || hi[i + 1] != h || lo[i + 1] != l;
-            if (next_head && !key_is_palindrome(p.K, h, l)) {
-                const u64 g = gpos[i];
-                key = ((unsigned long long)window_group(p, pk, g) << 32) | g;
-            } else nons = true;
-        }
+    if (c < n_cls) {
+        const u32 st = class_start[c], m = class_start[c + 1] - st;
+        const u32 fl = (u32)rec[st] & 0xFFu;
+        if (m == 1 && !(fl & 2u)) key = ((unsigned long long)(fl >> 2) << 32) | gpos[st];
+        else nons = true;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(key, o, 64);
         key = other < key ? other : key;
     }
-    const u64 bh = __ballot(head), bn = __ballot(nons);
+    const u64 bn = __ballot(nons);
     const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_reps[wv] = (u32)__popcll(bh); s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; }
+    if ((threadIdx.x & 63) == 0) { s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        blk_reps[blockIdx.x] = s_reps[0] + s_reps[1] + s_reps[2] + s_reps[3];
         blk_nons[blockIdx.x] = s_nons[0] + s_nons[1] + s_nons[2] + s_nons[3];
         unsigned long long m = s_min[0];
         for (int w = 1; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;
@@ -277,26 +392,22 @@ __global__ __launch_bounds__(256) void k_min_u64(const unsigned long long *__res
     }
 }
 
-// Marks representatives in the position bitmap and lists the classes with >= 2 entries
-// (rep<<32 | index of the class's first key), in key order, at offsets from the scan of blk_nons.
-__global__ __launch_bounds__(256) void k_class_emit(DevParams p, const u64 *__restrict__ hi, const u64 *__restrict__ lo,
-                                                    const u32 *__restrict__ gpos, u64 n, u32 *__restrict__ repmask,
+// Marks every class's representative (its first = lowest position, HTS:2573-2578) in the position bitmap
+// and lists the classes with >= 2 entries as rep<<32 | class index, at offsets from the scan of blk_nons.
+__global__ __launch_bounds__(256) void k_class_emit(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
+                                                    const u32 *__restrict__ class_start, u32 n_cls, u32 *__restrict__ repmask,
                                                     u64 *__restrict__ cls, const u64 *__restrict__ nons_off)
 {
     __shared__ u32 s_nons[4];
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     bool nons = false;
     u32 g = 0;
-    if (i < n) {
-        const u64 h = hi[i], l = lo[i];
-        const bool head = (i == 0) || hi[i - 1] != h || lo[i - 1] != l;
-        if (head) {
-            g = gpos[i];
-            atomicOr(&repmask[g >> 5], 1u << (31 - (g & 31)));
-            const bool next_head = (i + 1 == n) || hi[i + 1] != h || lo[i + 1] != l;
-            nons = !(next_head && !key_is_palindrome(p.K, h, l));
-        }
+    if (c < n_cls) {
+        const u32 st = class_start[c], m = class_start[c + 1] - st;
+        g = gpos[st];
+        atomicOr(&repmask[g >> 5], 1u << (31 - (g & 31)));
+        nons = !(m == 1 && !((u32)rec[st] & 2u));
     }
     const u64 bn = __ballot(nons);
     if (lane == 0) s_nons[wv] = (u32)__popcll(bn);
@@ -305,7 +416,7 @@ __global__ __launch_bounds__(256) void k_class_emit(DevParams p, const u64 *__re
         u32 pre = 0;
         for (int w = 0; w < wv; w++) pre += s_nons[w];
         const u64 at = nons_off[blockIdx.x] + pre + (u32)__popcll(bn & ((1ull << lane) - 1ull));
-        cls[at] = ((u64)g << 32) | (u64)(u32)i;
+        cls[at] = ((u64)g << 32) | (u64)c;
     }
 }
 
@@ -335,57 +446,44 @@ __global__ __launch_bounds__(256) void k_bitmap_emit(const u32 *__restrict__ bit
 }
 
 // ------------------------------------------------------------------ exact table pieces
-// cls[c] = rep<<32 | start, sorted by rep.  flags: bit0 palindrome, bit1 flip, bit2 rep strand, bit3 leading.
-__global__ __launch_bounds__(256) void k_class_info(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ hi,
-                                                    const u64 *__restrict__ lo, u64 n, const u64 *__restrict__ cls, u32 n_cls,
-                                                    const DevCounters *__restrict__ ctr, u32 *__restrict__ cls_m,
+// cls[k] = rep<<32 | class index, sorted by rep.  flags: bit0 palindrome, bit1 flip, bit2 rep strand, bit3 leading.
+__global__ __launch_bounds__(256) void k_class_info(const u64 *__restrict__ rec, const u32 *__restrict__ class_start,
+                                                    const u64 *__restrict__ cls, u32 n_cls, const DevCounters *__restrict__ ctr,
                                                     u32 *__restrict__ cls_flags, u32 *__restrict__ cls_entries)
 {
-    const u32 c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_cls) return;
-    const u64 rep = cls[c] >> 32, start = cls[c] & 0xFFFFFFFFull;
-    const u64 h = hi[start], l = lo[start];
-    u64 a = start + 1, b = n;
-    while (a < b) {
-        const u64 mid = (a + b) >> 1;
-        if (hi[mid] == h && lo[mid] == l) a = mid + 1; else b = mid;
-    }
-    const u32 m = (u32)(a - start);
-    const bool pal = key_is_palindrome(p.K, h, l);
-    u64 fh, fl;
-    load_window(p, pk, rep, fh, fl);
-    const bool strand = !(fh == h && fl == l);                 // canonical form is the reverse complement
-    const unsigned long long ord = ((unsigned long long)p.sig2[base_at(fh, fl, 0) * 4 + base_at(fh, fl, p.K - 1)] << 32) | rep;
-    const bool leading = ord < ctr->first_singleton_key;      // class id precedes the first singleton's (Q3)
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_cls) return;
+    const u64 rep = cls[k] >> 32;
+    const u32 c = (u32)cls[k];
+    const u32 st = class_start[c], m = class_start[c + 1] - st;
+    const u32 fl = (u32)rec[st] & 0xFFu;                        // flags of the representative's window
+    const bool pal = fl & 2u, strand = fl & 1u;
+    const unsigned long long ord = ((unsigned long long)(fl >> 2) << 32) | rep;
+    const bool leading = ord < ctr->first_singleton_key;       // class id precedes the first singleton's (Q3)
     const bool flip = strand && !leading;
-    cls_m[c] = m;
-    cls_flags[c] = (pal ? 1u : 0u) | (flip ? 2u : 0u) | (strand ? 4u : 0u) | (leading ? 8u : 0u);
-    cls_entries[c] = m * (pal ? 2u : 1u);
+    cls_flags[k] = (pal ? 1u : 0u) | (flip ? 2u : 0u) | (strand ? 4u : 0u) | (leading ? 8u : 0u);
+    cls_entries[k] = m * (pal ? 2u : 1u);
 }
 
 // entries of a class in the reference's list order (HTS:356-408): occurrences by position;
 // dir = strandSwitched (HTS:2552-2565), flipped when the representative's is 1 (HTS:424-432);
 // a palindromic K-mer contributes (0,pos),(1,pos) (Q2, HTS:2597-2616).
-__global__ __launch_bounds__(256) void k_class_entries(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ gpos,
-                                                       const u64 *__restrict__ cls, u32 n_cls, const u32 *__restrict__ cls_m,
+__global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
+                                                       const u32 *__restrict__ class_start, const u64 *__restrict__ cls, u32 n_cls,
                                                        const u32 *__restrict__ cls_flags, const u64 *__restrict__ ent_off,
                                                        u32 *__restrict__ ent, u8 *__restrict__ ent_dir)
 {
-    const u32 c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_cls) return;
-    const u64 start = cls[c] & 0xFFFFFFFFull;
-    const u32 m = cls_m[c], fl = cls_flags[c];
-    u64 o = ent_off[c];
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_cls) return;
+    const u32 c = (u32)cls[k];
+    const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[k];
+    u64 o = ent_off[k];
     for (u32 j = 0; j < m; j++) {
-        const u32 g = gpos[start + j];
+        const u32 g = gpos[st + j];
         if (fl & 1u) {
             ent[o] = g; ent_dir[o] = 0; ent[o + 1] = g; ent_dir[o + 1] = 1; o += 2;
         } else {
-            u64 hi, lo, rhi, rlo;
-            load_window(p, pk, g, hi, lo);
-            rc_window(p.K, hi, lo, rhi, rlo);
-            const u32 strand = ((rhi < hi) || (rhi == hi && rlo < lo)) ? 1u : 0u;
-            ent[o] = g; ent_dir[o] = (u8)(strand ^ ((fl >> 1) & 1u)); o++;
+            ent[o] = g; ent_dir[o] = (u8)(((u32)rec[st + j] & 1u) ^ ((fl >> 1) & 1u)); o++;
         }
     }
 }
@@ -693,18 +791,38 @@ void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_p
 {
     hipLaunchKernelGGL(k_contig_check, grid_for(p.n_contigs), dim3(256), 0, s, p, gpos_by_position, n, ctr);
 }
-void launch_class_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
-                        u32 *blk_reps, u32 *blk_nons, unsigned long long *blk_min, DevCounters *ctr)
+void launch_kmer_emit_hashed(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 n_blocks,
+                             u64 *rec, u32 *gpos)
 {
-    if (!n) return;
-    const dim3 g = grid_for(n);
-    hipLaunchKernelGGL(k_class_count, g, dim3(256), 0, s, p, pk, hi, lo, gpos, n, blk_reps, blk_nons, blk_min);
+    hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, p, pk, bad, block_off, rec, gpos);
+}
+void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
+                        u32 *head_flag, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr)
+{
+    if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_flag, mixed_list, mixed_cap, ctr);
+}
+void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, const u32 *mixed_list,
+                      u32 n_mixed, DevCounters *ctr)
+{
+    if (n_mixed) hipLaunchKernelGGL(k_mixed_fix, dim3((n_mixed + 63) / 64), dim3(64), 0, s, p, pk, rec, gpos, n, hb, mixed_list, n_mixed, ctr);
+}
+void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
+                            u32 *head_flag, u64 *rec)
+{
+    if (n) hipLaunchKernelGGL(k_heads_from_keys, grid_for(n), dim3(256), 0, s, p, pk, hi, lo, gpos, n, head_flag, rec);
+}
+void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
+                        unsigned long long *blk_min, DevCounters *ctr)
+{
+    if (!n_cls) return;
+    const dim3 g = grid_for(n_cls);
+    hipLaunchKernelGGL(k_class_count, g, dim3(256), 0, s, rec, gpos, class_start, n_cls, blk_nons, blk_min);
     hipLaunchKernelGGL(k_min_u64, dim3(g.x < 64 ? g.x : 64), dim3(256), 0, s, blk_min, (u64)g.x, &ctr->first_singleton_key);
 }
-void launch_class_emit(hipStream_t s, const DevParams &p, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n, u32 *repmask,
-                       u64 *cls, const u64 *nons_off)
+void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *repmask, u64 *cls,
+                       const u64 *nons_off)
 {
-    if (n) hipLaunchKernelGGL(k_class_emit, grid_for(n), dim3(256), 0, s, p, hi, lo, gpos, n, repmask, cls, nons_off);
+    if (n_cls) hipLaunchKernelGGL(k_class_emit, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, n_cls, repmask, cls, nons_off);
 }
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks)
 {
@@ -714,15 +832,15 @@ void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *
 {
     hipLaunchKernelGGL(k_bitmap_emit, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_off, out);
 }
-void launch_class_info(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, u64 n, const u64 *cls,
-                       u32 n_cls, const DevCounters *ctr, u32 *cls_m, u32 *cls_flags, u32 *cls_entries)
+void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,
+                       u32 *cls_flags, u32 *cls_entries)
 {
-    if (n_cls) hipLaunchKernelGGL(k_class_info, grid_for(n_cls), dim3(256), 0, s, p, pk, hi, lo, n, cls, n_cls, ctr, cls_m, cls_flags, cls_entries);
+    if (n_cls) hipLaunchKernelGGL(k_class_info, grid_for(n_cls), dim3(256), 0, s, rec, class_start, cls, n_cls, ctr, cls_flags, cls_entries);
 }
-void launch_class_entries(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, const u64 *cls, u32 n_cls,
-                          const u32 *cls_m, const u32 *cls_flags, const u64 *ent_off, u32 *ent, u8 *ent_dir)
+void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, const u64 *cls, u32 n_cls,
+                          const u32 *cls_flags, const u64 *ent_off, u32 *ent, u8 *ent_dir)
 {
-    if (n_cls) hipLaunchKernelGGL(k_class_entries, grid_for(n_cls), dim3(256), 0, s, p, pk, gpos, cls, n_cls, cls_m, cls_flags, ent_off, ent, ent_dir);
+    if (n_cls) hipLaunchKernelGGL(k_class_entries, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, cls, n_cls, cls_flags, ent_off, ent, ent_dir);
 }
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off, const u32 *ent,
                         const u8 *ent_dir, u8 *merge_prev)

@@ -50,7 +50,7 @@ struct PairRec { u32 p1, p2, meta; };
 
 // counters block kept on the device for one run
 struct DevCounters {
-    unsigned long long n_reps, n_nonsingle, first_singleton_key, n_pairs, n_candidates, n_dirty, format_errors;
+    unsigned long long n_mixed, fallback, first_singleton_key, n_pairs, n_candidates, n_dirty, format_errors;
     unsigned long long empty_contigs;
 };
 
@@ -60,16 +60,24 @@ void launch_kmer_count(hipStream_t s, const DevParams &p, const u32 *bad, u32 *b
 void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
                       u32 n_blocks, u64 *key_hi, u64 *key_lo, u32 *gpos);
 void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);
-void launch_class_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
-                        u64 n, u32 *blk_reps, u32 *blk_nons, unsigned long long *blk_min, DevCounters *ctr);
-void launch_class_emit(hipStream_t s, const DevParams &p, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
-                       u32 *repmask, u64 *cls /* rep<<32|start */, const u64 *nons_off);
+void launch_kmer_emit_hashed(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
+                             u32 n_blocks, u64 *rec, u32 *gpos);
+void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
+                        u32 *head_flag, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr);
+void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb,
+                      const u32 *mixed_list, u32 n_mixed, DevCounters *ctr);
+void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
+                            u64 n, u32 *head_flag, u64 *rec);
+void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
+                        unsigned long long *blk_min, DevCounters *ctr);
+void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *repmask,
+                       u64 *cls /* rep<<32 | class index */, const u64 *nons_off);
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks);
 void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out);
-void launch_class_info(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, u64 n,
-                       const u64 *cls, u32 n_cls, const DevCounters *ctr, u32 *cls_m, u32 *cls_flags, u32 *cls_entries);
-void launch_class_entries(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, const u64 *cls, u32 n_cls,
-                          const u32 *cls_m, const u32 *cls_flags, const u64 *ent_off, u32 *ent /* gpos */, u8 *ent_dir);
+void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,
+                       u32 *cls_flags, u32 *cls_entries);
+void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, const u64 *cls, u32 n_cls,
+                          const u32 *cls_flags, const u64 *ent_off, u32 *ent /* gpos */, u8 *ent_dir);
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off,
                         const u32 *ent, const u8 *ent_dir, u8 *merge_prev);
 void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out);

@@ -65,6 +65,8 @@ typedef struct cora_hip_stats {
     float ms_sort_scatter;        /* time inside radix scatter launches (the dominant kernel) */
     uint32_t n_sort_scatter;      /* number of those launches */
     uint64_t sort_scatter_bytes;  /* algorithmic bytes those launches moved (read + write of every record) */
+    uint64_t hash_mixed_runs;     /* equal-hash runs that held different K-mers and were re-ordered by key */
+    uint64_t full_key_fallback;   /* 1 if the exact stage had to redo its sort on the full 128-bit keys */
 } cora_hip_stats;
 
 typedef struct cora_hip_job cora_hip_job;   /* opaque */

@@ -200,9 +200,12 @@ INPUTS = {
     "syn": inp_syn, "pal": inp_pal, "q": inp_q, "q4a": lambda: inp_q4(50), "q4b": lambda: inp_q4(51),
     "lowcx": inp_lowcx, "multi": inp_multi, "fam": inp_fam,
     "ecoli_like": lambda: synth.workload_ecoli_like(2024),
+    "chr20_like": lambda: synth.workload_chr20_like(20, 64_000_000),     # bench.py's N=1 workload (configs[1])
 }
 # inputs too big to commit are rebuilt from the recipe by the tests (sha256 pinned)
-RECIPE_ONLY = {"ecoli_like"}
+RECIPE_ONLY = {"ecoli_like", "chr20_like"}
+# cases whose tables are too big to commit: only their sha256 and sizes are pinned
+HASH_ONLY = {"chr20_like_k50_d2"}
 
 #        case name        input   K   d  p   t  L
 CASES = [
@@ -226,6 +229,7 @@ CASES = [
     ("fam_k50_d2",        "fam",  50, 2, 1,  4, 0),
     ("fam_k48_d3",        "fam",  48, 3, 2,  2, 0),
     ("ecoli_like_k50_d2", "ecoli_like", 50, 2, 1, 8, 0),
+    ("chr20_like_k50_d2", "chr20_like", 50, 2, 1, 8, 0),
 ]
 
 
@@ -267,14 +271,16 @@ def main():
         if r.returncode != 0:
             print(r.stdout[-3000:])
             raise SystemExit("reference failed on %s (exit %d)" % (name, r.returncode))
-        dst = synth.ensure_dir(os.path.join(HERE, "cases", name))
-        for fn in ("Exact", "Exact.itemCount", "Inexact", "Inexact.itemCount"):
-            shutil.copy(os.path.join(out, fn), os.path.join(dst, fn))
+        if name not in HASH_ONLY:
+            dst = synth.ensure_dir(os.path.join(HERE, "cases", name))
+            for fn in ("Exact", "Exact.itemCount", "Inexact", "Inexact.itemCount"):
+                shutil.copy(os.path.join(out, fn), os.path.join(dst, fn))
         manifest["cases"][name] = {
             "input": inp, "K": K, "d": d, "p": p, "t": t, "L": L,
             "exact_nodes": int(open(ex + ".itemCount").read()),
             "inexact_nodes": int(open(inx + ".itemCount").read()),
             "exact_sha256": sha256(ex), "inexact_sha256": sha256(inx),
+            "exact_bytes": os.path.getsize(ex), "inexact_bytes": os.path.getsize(inx), "hash_only": name in HASH_ONLY,
         }
         print("%-22s exact %6d nodes %8d B   inexact %7d nodes %9d B" % (
             name, manifest["cases"][name]["exact_nodes"], os.path.getsize(ex),

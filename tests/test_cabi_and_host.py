@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(hip.Contig) == 16
     assert ctypes.sizeof(hip.Params) == 6 * 4 + 16 + 256
-    assert ctypes.sizeof(hip.Stats) == 11 * 8 + 7 * 4 + 4 + 8
+    assert ctypes.sizeof(hip.Stats) == 11 * 8 + 7 * 4 + 4 + 8 + 16
 
 
 def test_executable_argument_errors_need_no_gpu(tmp_path):
@@ -104,7 +104,7 @@ def test_fasta_geometry_and_image(tmp_path):
 
 def test_recipe_only_inputs_still_reproduce():
     for name, meta in helpers.MANIFEST["inputs"].items():
-        if meta["recipe_only"]:
+        if meta["recipe_only"] and meta["bases"] <= 10_000_000:
             helpers.input_path(name)        # asserts the sha256
 
 

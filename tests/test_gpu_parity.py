@@ -119,7 +119,7 @@ def test_pack_and_kmers_match_numpy(tmp_path):
 
 
 # ------------------------------------------------------------------ whole tables vs the real reference
-@pytest.mark.parametrize("name", sorted(helpers.MANIFEST["cases"]))
+@pytest.mark.parametrize("name", sorted(n for n, c in helpers.MANIFEST["cases"].items() if not c.get("hash_only")))
 def test_tables_match_reference_golden(name):
     c, want = helpers.golden_case(name)
     e, en, i, inn, st = hip.build_tables(helpers.input_path(c["input"]), c["K"], c["d"],
@@ -159,3 +159,44 @@ def test_seeded_genomes_match_oracle(seed, K, d, p, t, tmp_path):
     assert i == helpers.read(oinx)
     assert str(en) == helpers.read(oex + ".itemCount").decode().strip()
     assert str(inn) == helpers.read(oinx + ".itemCount").decode().strip()
+
+
+# ------------------------------------------------------------------ hashed exact sort: collisions must not change a byte
+@pytest.mark.parametrize("bits,expect", [(24, "mixed"), (16, "any"), (8, "fallback")])
+@pytest.mark.parametrize("name", ["syn_k50_d2", "lowcx_k50_d2", "fam_k50_d2", "q_k50_d2_p10"])
+def test_hash_collisions_are_repaired(name, bits, expect, monkeypatch):
+    """CORA_HASH_BITS shrinks the hash the exact stage sorts on, which forces different K-mers into the
+    same run: few bits -> the in-place repair (k_mixed_fix), very few -> the full 128-bit key sort."""
+    monkeypatch.setenv("CORA_HASH_BITS", str(bits))
+    c, want = helpers.golden_case(name)
+    e, en, i, inn, st = hip.build_tables(helpers.input_path(c["input"]), c["K"], c["d"],
+                                         helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
+    assert e == helpers.read(os.path.join(want, "Exact")) and i == helpers.read(os.path.join(want, "Inexact"))
+    if expect == "fallback" and st["kmers"] > 100000:
+        assert st["full_key_fallback"] == 1
+    if expect == "mixed" and st["kmers"] > 100000:
+        assert st["hash_mixed_runs"] > 0
+
+
+# ------------------------------------------------------------------ the benchmark workload at full size
+def test_full_size_workload_matches_reference_hash():
+    """bench.py's N=1 workload (64 Mbp chr20_like, K=50, d=2): the real reference's tables for it are pinned
+    by sha256 in the manifest (made by tests/golden/make_golden.py; too big to commit)."""
+    import hashlib
+    c = helpers.MANIFEST["cases"]["chr20_like_k50_d2"]
+    contigs = synth.workload_chr20_like(20, 64_000_000)
+    image, W, geom = synth.fasta_image(contigs, 60)
+    assert hashlib.sha256(image.tobytes()).hexdigest() == helpers.MANIFEST["inputs"]["chr20_like"]["sha256"]
+    job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]))
+    job.set_reference(image, W, geom)
+    job.run()
+    e, en, i, inn = job.tables()
+    first = (e, i)
+    assert (en, inn) == (c["exact_nodes"], c["inexact_nodes"])
+    assert (len(e), len(i)) == (c["exact_bytes"], c["inexact_bytes"])
+    assert hashlib.sha256(e).hexdigest() == c["exact_sha256"]
+    assert hashlib.sha256(i).hexdigest() == c["inexact_sha256"]
+    job.run()                                   # idempotent: a second build over the same image gives the same bytes
+    e2, _, i2, _ = job.tables()
+    assert (e2, i2) == first
+    job.close()
