@@ -497,20 +497,33 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     u64 n_pairs = 0;
     {
         RCQ(pairs.alloc(pair_cap));
-        DBuf<u64> codes, codes_tmp, blk_off, cand_off, scr, tots;
-        DBuf<u32> blk_recs, blk_cand;
+        DBuf<u64> codes, codes_tmp, blk_off, scr, tots;
+        DBuf<u32> blk_active;
         const u32 vb = (u32)((NR + 255) / 256);
         RCQ(codes.alloc(NR)); RCQ(codes_tmp.alloc(NR));
-        RCQ(blk_recs.alloc(vb)); RCQ(blk_cand.alloc(vb)); RCQ(blk_off.alloc(vb)); RCQ(cand_off.alloc(vb));
-        RCQ(scr.alloc(scan_scratch_elems(vb))); RCQ(tots.alloc(2));
+        RCQ(blk_active.alloc(vb)); RCQ(blk_off.alloc(vb));
+        RCQ(scr.alloc(scan_scratch_elems(NR / 4 + vb + 4096))); RCQ(tots.alloc(2));
         for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
             SortArrays ck, ct;
             ck.a = codes.p; ct.a = codes_tmp.p;
             launch_seed_codes(s, dp, job->pk.p, reps.p, NR, seed, ck.a);
             if (radix_sort(s, ck, ct, NR, 32, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-            launch_verify_count(s, dp, job->pk.p, ck.a, NR, seed, blk_recs.p, blk_cand.p);
-            if (exclusive_scan_u32_to_u64(s, blk_recs.p, blk_off.p, vb, scr.p, tots.p)) return fail(100, "scan launch failed");
-            if (exclusive_scan_u32_to_u64(s, blk_cand.p, cand_off.p, vb, scr.p, tots.p + 1)) return fail(100, "scan launch failed");
+            // records with an earlier run member (or a palindromic code), compacted
+            launch_active_count(s, ck.a, NR, blk_active.p);
+            if (exclusive_scan_u32_to_u64(s, blk_active.p, blk_off.p, vb, scr.p, tots.p)) return fail(100, "scan launch failed");
+            u64 n_active = 0;
+            HIPQ(hipMemcpyAsync(&n_active, tots.p, sizeof n_active, hipMemcpyDeviceToHost, s));
+            HIPQ(hipStreamSynchronize(s));
+            if (n_active == 0) continue;
+            if (n_active >= (1ull << 32)) return fail(19, "too many run members");
+            DBuf<u32> active, cnt_recs, cnt_cand;
+            DBuf<u64> rec_off, cand_off, scr_a;
+            RCQ(active.alloc(n_active)); RCQ(cnt_recs.alloc(n_active)); RCQ(cnt_cand.alloc(n_active));
+            RCQ(rec_off.alloc(n_active)); RCQ(cand_off.alloc(n_active)); RCQ(scr_a.alloc(scan_scratch_elems(n_active)));
+            launch_active_emit(s, ck.a, NR, blk_off.p, active.p);
+            launch_verify_count(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, cnt_recs.p, cnt_cand.p);
+            if (exclusive_scan_u32_to_u64(s, cnt_recs.p, rec_off.p, n_active, scr_a.p, tots.p)) return fail(100, "scan launch failed");
+            if (exclusive_scan_u32_to_u64(s, cnt_cand.p, cand_off.p, n_active, scr_a.p, tots.p + 1)) return fail(100, "scan launch failed");
             u64 totals[2] = {0, 0};
             HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
             HIPQ(hipStreamSynchronize(s));
@@ -524,7 +537,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
                 std::swap(pairs.p, bigger.p); std::swap(pairs.n, bigger.n);
                 pair_cap = want;
             }
-            if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, NR, seed, blk_off.p, pairs.p + n_pairs);
+            if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, rec_off.p, pairs.p + n_pairs);
             n_pairs += totals[0];
         }
         st.hom_pairs = n_pairs;

@@ -574,90 +574,111 @@ __device__ __forceinline__ u32 judge(const DevParams &p, Mism m, int seed, u32 d
     return meta_pack(dir, o1, o2, o3, (u32)(seed - 1), 0, 0);
 }
 
-// One thread per representative in (canonical code, position) order.  It is compared with every
-// EARLIER representative of its equal-code run (HTS:2753-2762: k-mer 1 is the later one).
-// The orientation is the one in which the seed positions agree; a palindromic code agrees in both,
-// and the reference then compares both ways and meets every earlier entry twice (Q1, HTS:2769-2792).
-//
-// Two passes and no atomics (a counter bumped once per wave was 12 ns x 10^6 waves = most of the
-// first profile): WRITE=false counts each block's records and comparisons, the host scans the block
-// counts, WRITE=true repeats the comparisons and stores the records at block offset + rank.  Record
-// order is therefore deterministic: by (code, position) of k-mer 1, then later partners first.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ codes, u64 n_reps,
-                                                int seed, u32 *__restrict__ blk_recs, u32 *__restrict__ blk_cand,
-                                                const u64 *__restrict__ blk_off, PairRec *__restrict__ pairs)
+// Which records of the code-sorted list have anything to meet: every member of an equal-code run except
+// its first, plus every record with a palindromic code (it meets itself, Q1).  On a random genome that is
+// about 1.5 % of the records, one per wave: the verification kernels therefore run over the compacted list
+// of such records (all 64 lanes busy with gathers) instead of over all records.
+__global__ __launch_bounds__(256) void k_active_count(const u64 *__restrict__ codes, u64 n_reps, u32 *__restrict__ blk_active)
 {
-    __shared__ u32 l4[4];
-    constexpr u32 INV = 0xFFFFFFFFu;
+    __shared__ u32 ws[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool act = false;
+    if (i < n_reps) {
+        const u32 code = (u32)(codes[i] >> 32);
+        act = (i > 0 && (u32)(codes[i - 1] >> 32) == code) || rc_code(code) == code;
+    }
+    const u64 bal = __ballot(act);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_active[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void k_active_emit(const u64 *__restrict__ codes, u64 n_reps, const u64 *__restrict__ blk_off,
+                                                     u32 *__restrict__ active)
+{
+    __shared__ u32 ws[4];
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool act = false;
+    if (i < n_reps) {
+        const u32 code = (u32)(codes[i] >> 32);
+        act = (i > 0 && (u32)(codes[i - 1] >> 32) == code) || rc_code(code) == code;
+    }
+    const u64 bal = __ballot(act);
+    if (lane == 0) ws[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    if (!act) return;
+    u32 pre = 0;
+    for (int w = 0; w < wv; w++) pre += ws[w];
+    active[blk_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = (u32)i;
+}
+
+// One thread per active record i (k-mer 1).  It is compared with every EARLIER record of its equal-code
+// run (HTS:2753-2762: k-mer 1 is the later one).  The orientation is the one in which the seed positions
+// agree; a palindromic code agrees in both, and the reference then compares both ways and meets every
+// earlier entry twice (Q1, HTS:2769-2792).
+//
+// Two passes and no atomics (a counter bumped once per wave was 12 ns x 10^6 waves = most of the first
+// profile): WRITE=false stores each thread's record and comparison counts, the counts are scanned, WRITE=true
+// repeats the comparisons and stores the records at the scanned offsets.  The record order is deterministic:
+// by (code, position) of k-mer 1, then later partners first.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ codes,
+                                                const u32 *__restrict__ active, u32 n_active, int seed, u32 *__restrict__ cnt_recs,
+                                                u32 *__restrict__ cnt_cand, const u64 *__restrict__ rec_off, PairRec *__restrict__ pairs)
+{
+    constexpr u32 INV = 0xFFFFFFFFu;
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_active) return;
+    const u64 i = active[t];
     u32 nrec = 0, ncand = 0;
-    u64 at = 0;
-    // in the write pass the records of a thread go to consecutive slots; its first slot needs the
-    // block-wide scan of the counts, so the thread first counts (cheap: candidates are few), then writes
-    for (int pass = WRITE ? 0 : 1; pass < 2; pass++) {
-        const bool store = WRITE && pass == 1;
-        if (pass == 1 && WRITE) {
-            const u32 pre = block_excl_scan_u32(nrec, l4, nullptr);
-            at = blk_off[blockIdx.x] + pre;
-        }
-        if (i < n_reps) {
-            const u64 ci = codes[i];
-            const u32 code = (u32)(ci >> 32), gi = (u32)ci;
-            const bool pal = rc_code(code) == code;
-            const bool run_head = (i == 0) || (u32)(codes[i - 1] >> 32) != code;
-            if (!run_head || pal) {
-                u64 ih, il;
-                load_window(p, pk, gi, ih, il);
-                const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
-                if (pal) {                                  // second pass starts with the k-mer itself (HTS:2781-2787)
-                    u64 rh, rl;
-                    rc_window(p.K, ih, il, rh, rl);
-                    const u32 mr = judge(p, mism_of(ih, il, rh, rl), seed, 1);
-                    if (!store) ncand++;
-                    if (mr != INV) {
-                        if (store) { pairs[at].p1 = gi; pairs[at].p2 = gi; pairs[at].meta = mr | (1u << 24); at++; }
-                        else nrec++;
-                    }
-                }
-                for (u64 j = i; j-- > 0;) {
-                    const u64 cj = codes[j];
-                    if ((u32)(cj >> 32) != code) break;
-                    const u32 gj = (u32)cj;
-                    u64 jh, jl, rh, rl;
-                    load_window(p, pk, gj, jh, jl);
-                    rc_window(p.K, jh, jl, rh, rl);
-                    const Mism same = mism_of(ih, il, jh, jl), rev = mism_of(ih, il, rh, rl);
-                    u32 mf = INV, mr = INV, mr_extra = 0;
-                    if (pal) {
-                        if (!store) ncand += 4;
-                        mf = judge(p, same, seed, 0);
-                        mr = judge(p, rev, seed, 1);
-                        mr_extra = 1u << 24;
-                    } else {
-                        if (!store) ncand++;
-                        const bool same_ok = ((same.hi & smh) | (same.lo & sml)) == 0;
-                        if (same_ok) mf = judge(p, same, seed, 0); else mr = judge(p, rev, seed, 1);
-                    }
-                    const u32 copies = pal ? 2u : 1u;       // palindromic code: every record twice (Q1)
-                    if (mf != INV) {
-                        if (store) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mf | (c << 25); }
-                        else nrec += copies;
-                    }
-                    if (mr != INV) {
-                        if (store) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mr | mr_extra | (c << 25); }
-                        else nrec += copies;
-                    }
-                }
-            }
+    u64 at = WRITE ? rec_off[t] : 0;
+    const u64 ci = codes[i];
+    const u32 code = (u32)(ci >> 32), gi = (u32)ci;
+    const bool pal = rc_code(code) == code;
+    u64 ih, il;
+    load_window(p, pk, gi, ih, il);
+    const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
+    if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
+        u64 rh, rl;
+        rc_window(p.K, ih, il, rh, rl);
+        const u32 mr = judge(p, mism_of(ih, il, rh, rl), seed, 1);
+        ncand++;
+        if (mr != INV) {
+            if (WRITE) { pairs[at].p1 = gi; pairs[at].p2 = gi; pairs[at].meta = mr | (1u << 24); at++; }
+            else nrec++;
         }
     }
-    if (!WRITE) {
-        u32 tr, tc;
-        (void)block_excl_scan_u32(nrec, l4, &tr);
-        (void)block_excl_scan_u32(ncand, l4, &tc);
-        if (threadIdx.x == 0) { blk_recs[blockIdx.x] = tr; blk_cand[blockIdx.x] = tc; }
+    for (u64 j = i; j-- > 0;) {
+        const u64 cj = codes[j];
+        if ((u32)(cj >> 32) != code) break;
+        const u32 gj = (u32)cj;
+        u64 jh, jl, rh, rl;
+        load_window(p, pk, gj, jh, jl);
+        rc_window(p.K, jh, jl, rh, rl);
+        const Mism same = mism_of(ih, il, jh, jl), rev = mism_of(ih, il, rh, rl);
+        u32 mf = INV, mr = INV, mr_extra = 0;
+        if (pal) {
+            ncand += 4;
+            mf = judge(p, same, seed, 0);
+            mr = judge(p, rev, seed, 1);
+            mr_extra = 1u << 24;
+        } else {
+            ncand++;
+            const bool same_ok = ((same.hi & smh) | (same.lo & sml)) == 0;
+            if (same_ok) mf = judge(p, same, seed, 0); else mr = judge(p, rev, seed, 1);
+        }
+        const u32 copies = pal ? 2u : 1u;                   // palindromic code: every record twice (Q1)
+        if (mf != INV) {
+            if (WRITE) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mf | (c << 25); }
+            else nrec += copies;
+        }
+        if (mr != INV) {
+            if (WRITE) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mr | mr_extra | (c << 25); }
+            else nrec += copies;
+        }
     }
+    if (!WRITE) { cnt_recs[t] = nrec; cnt_cand[t] = ncand; }
 }
 
 // ------------------------------------------------------------------ directed items
@@ -851,17 +872,25 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
 {
     if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
 }
-void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed, u32 *blk_recs,
-                         u32 *blk_cand)
+void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active)
 {
-    if (n_reps) hipLaunchKernelGGL((k_verify<false>), grid_for(n_reps), dim3(256), 0, s, p, pk, codes, n_reps, seed, blk_recs, blk_cand,
-                                   (const u64 *)nullptr, (PairRec *)nullptr);
+    if (n_reps) hipLaunchKernelGGL(k_active_count, grid_for(n_reps), dim3(256), 0, s, codes, n_reps, blk_active);
 }
-void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, u64 n_reps, int seed, const u64 *blk_off,
-                         PairRec *pairs)
+void launch_active_emit(hipStream_t s, const u64 *codes, u64 n_reps, const u64 *blk_off, u32 *active)
 {
-    if (n_reps) hipLaunchKernelGGL((k_verify<true>), grid_for(n_reps), dim3(256), 0, s, p, pk, codes, n_reps, seed, (u32 *)nullptr,
-                                   (u32 *)nullptr, blk_off, pairs);
+    if (n_reps) hipLaunchKernelGGL(k_active_emit, grid_for(n_reps), dim3(256), 0, s, codes, n_reps, blk_off, active);
+}
+void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
+                         u32 *cnt_recs, u32 *cnt_cand)
+{
+    if (n_active) hipLaunchKernelGGL((k_verify<false>), grid_for(n_active), dim3(256), 0, s, p, pk, codes, active, n_active, seed, cnt_recs,
+                                     cnt_cand, (const u64 *)nullptr, (PairRec *)nullptr);
+}
+void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
+                         const u64 *rec_off, PairRec *pairs)
+{
+    if (n_active) hipLaunchKernelGGL((k_verify<true>), grid_for(n_active), dim3(256), 0, s, p, pk, codes, active, n_active, seed,
+                                     (u32 *)nullptr, (u32 *)nullptr, rec_off, pairs);
 }
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta)
 {
