@@ -123,7 +123,8 @@ def main():
             "config": {"workload": "chr20_like synthetic contig, %d bp per GPU, K=%d, d=%d, 60-column FASTA image resident in HBM; "
                                    "output = both tables as bytes in host memory" % (a.bases, K, d),
                        "kmers_per_gpu": int(st["kmers"]), "hom_pairs": int(st["hom_pairs"]), "inexact_nodes": int(st["inexact_nodes"]),
-                       "exact_nodes": int(st["exact_nodes"]), "parallelism": "1 reference per GPU" if world > 1 else "1 GPU"},
+                       "exact_nodes": int(st["exact_nodes"]), "hash_mixed_runs": int(st["hash_mixed_runs"]),
+                       "full_key_fallback": int(st["full_key_fallback"]), "dirty_nodes": int(st["dirty_nodes"]), "big_nodes": int(st["big_nodes"]), "parallelism": "1 reference per GPU" if world > 1 else "1 GPU"},
             "stage_ms": {k: round(st[k], 3) for k in ("ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total")},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter (LSD radix scatter, all sorts of the path)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -196,11 +196,19 @@ __device__ __forceinline__ u32 kmer_flags(const DevParams &p, u64 hi, u64 lo, u6
     return (use_rc ? 1u : 0u) | (pal ? 2u : 0u) | (grp << 2);
 }
 
+// splitmix64 finaliser: full avalanche in both directions.  (A first version combined the two key words
+// by multiplications only; a multiplication never moves a difference DOWN, so K-mers of one repeat family
+// that differed in the top bits of both words collided a thousand times more often than chance.)
+__device__ __forceinline__ u64 mix64(u64 z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
 __device__ __forceinline__ u64 key_hash(u64 hi, u64 lo)
 {
-    u64 h = hi * 0x9E3779B97F4A7C15ull ^ ((lo << 29) | (lo >> 35)) * 0xBF58476D1CE4E5B9ull;
-    h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
-    return h;
+    return mix64(mix64(hi) + lo * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull);
 }
 
 __device__ __forceinline__ void canonical_at(const DevParams &p, const u64 *__restrict__ pk, u64 g, u64 &chi, u64 &clo)
