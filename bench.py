@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bases", type=int, default=64_000_000, help="reference length (default: chr20-sized)")
-    ap.add_argument("--cpu-sample", type=int, default=2_500_000, help="bases of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="bases of the CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
