@@ -1,154 +1,8 @@
 // job.hip -- C-ABI of libcora_hip.so (include/cora_hip.h) and the stage orchestration of one
 // table build on one MI355X.  HTS = /root/reference/homTable_setup.cpp.
-#include "../../include/cora_hip.h"
-#include "finish.hpp"
-#include "kernels.hpp"
-#include "radix_sort.hpp"
-
-#include <chrono>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <string>
-#include <vector>
+#include "job_internal.hpp"
 
 using namespace cora;
-
-static thread_local std::string g_err;
-static int g_device = -1;
-
-static int fail(int code, const char *fmt, ...)
-{
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code ? code : 1;
-}
-
-#define HIPQ(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(100, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-#define RCQ(x) do { int r_ = (x); if (r_) return r_; } while (0)
-
-// Device memory pool of one job: stages allocate and release dozens of arrays per run and
-// hipMalloc/hipFree of large blocks cost milliseconds each (hipFree also synchronises the device),
-// so released blocks are kept and handed out again (same sizes recur every run).
-struct DevPool {
-    struct Block { void *p; size_t bytes; bool free; };
-    std::vector<Block> blocks;
-    void *get(size_t bytes)
-    {
-        bytes = (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
-        int best = -1;
-        for (size_t i = 0; i < blocks.size(); i++)
-            if (blocks[i].free && blocks[i].bytes >= bytes && blocks[i].bytes <= bytes + bytes / 4 + (4u << 20) &&
-                (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = (int)i;
-        if (best >= 0) { blocks[best].free = false; return blocks[best].p; }
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            trim();                                          // give cached blocks back and retry once
-            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        }
-        blocks.push_back({p, bytes, false});
-        return p;
-    }
-    void put(void *p)
-    {
-        for (auto &b : blocks) if (b.p == p) { b.free = true; return; }
-    }
-    void trim()
-    {
-        std::vector<Block> keep;
-        for (auto &b : blocks) { if (b.free) (void)hipFree(b.p); else keep.push_back(b); }
-        blocks.swap(keep);
-    }
-    void destroy()
-    {
-        for (auto &b : blocks) (void)hipFree(b.p);
-        blocks.clear();
-    }
-};
-static thread_local DevPool *g_pool = nullptr;       // pool of the job the calling thread is working for
-
-template <typename T>
-struct DBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    DevPool *pool = nullptr;
-    int alloc(size_t count)
-    {
-        release();
-        if (count == 0) count = 1;
-        pool = g_pool;
-        if (pool) p = (T *)pool->get(count * sizeof(T));
-        else if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) p = nullptr;
-        if (!p) return fail(101, "device allocation of %zu bytes failed", count * sizeof(T));
-        n = count;
-        return 0;
-    }
-    void release()
-    {
-        if (p) { if (pool) pool->put(p); else (void)hipFree(p); }
-        p = nullptr; n = 0;
-    }
-    ~DBuf() { release(); }
-    DBuf() {}
-    DBuf(const DBuf &) = delete;
-    DBuf &operator=(const DBuf &) = delete;
-};
-
-// grow-only pinned host array for results copied back every run
-template <typename T>
-struct HBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t count)
-    {
-        if (count <= cap) return 0;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-        const size_t want = count + count / 8 + 1024;
-        if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) { p = nullptr; return fail(101, "pinned host allocation of %zu bytes failed", want * sizeof(T)); }
-        cap = want;
-        return 0;
-    }
-    ~HBuf() { if (p) (void)hipHostFree(p); }
-};
-
-struct PoolScope {                                       // binds a job's pool to the calling thread for one API call
-    DevPool *prev;
-    explicit PoolScope(DevPool *p) : prev(g_pool) { g_pool = p; }
-    ~PoolScope() { g_pool = prev; }
-};
-
-struct cora_hip_job {
-    cora_hip_params prm;
-    HostGenome hg;
-    DevParams dp;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool have_ref = false;
-    uint64_t genome_bases = 0;
-    DBuf<u8> raw;
-    DBuf<u64> d_gstart, d_off;
-    DBuf<u32> d_len, d_window;
-    DBuf<u64> pk;
-    DBuf<u32> bad;
-    DBuf<DevCounters> ctr;
-    SortScratch sort_scratch;
-    SortTiming sort_timing;
-    DevPool pool;
-    HBuf<u64> h_cls, h_ent_off, h_key, h_packed;
-    HBuf<u32> h_cls_entries, h_ent, h_meta, h_node_start;
-    HBuf<u8> h_ent_dir, h_merge_prev;
-    HBuf<int16_t> h_blen;
-    int host_threads = 8;
-    int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
-    ByteBuf exact_bytes, inexact_bytes;
-    cora_hip_stats stats;
-};
 
 extern "C" const char *cora_hip_last_error(void) { return g_err.c_str(); }
 
@@ -270,35 +124,6 @@ extern "C" int cora_hip_job_set_reference(cora_hip_job *job, const uint8_t *imag
     RCQ(job->ctr.alloc(1));
     HIPQ(hipStreamSynchronize(job->stream));
     job->have_ref = true;
-    return 0;
-}
-
-static int read_counters(cora_hip_job *job, DevCounters &h)
-{
-    HIPQ(hipMemcpyAsync(&h, job->ctr.p, sizeof h, hipMemcpyDeviceToHost, job->stream));
-    HIPQ(hipStreamSynchronize(job->stream));
-    return 0;
-}
-static int write_counters(cora_hip_job *job, const DevCounters &h)
-{
-    HIPQ(hipMemcpyAsync(job->ctr.p, &h, sizeof h, hipMemcpyHostToDevice, job->stream));
-    HIPQ(hipStreamSynchronize(job->stream));
-    return 0;
-}
-
-static int bits_for(u64 G)
-{
-    int b = 1;
-    while (b < 32 && (1ull << b) < G) b++;
-    return b;
-}
-
-template <typename T>
-static int d2h(cora_hip_job *job, HBuf<T> &dst, View<T> &view, const T *src, size_t n)
-{
-    RCQ(dst.reserve(n));
-    if (n) HIPQ(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyDeviceToHost, job->stream));
-    view.p = dst.p; view.n = n;
     return 0;
 }
 
