@@ -146,6 +146,7 @@ struct cora_hip_job {
     HBuf<u8> h_ent_dir, h_merge_prev;
     HBuf<int16_t> h_blen;
     int host_threads = 8;
+    struct ShardState *shard = nullptr;   // multi-GPU stage state (shard.hip)
     int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
     ByteBuf exact_bytes, inexact_bytes;
     cora_hip_stats stats;
@@ -180,3 +181,37 @@ inline int d2h(cora_hip_job *job, HBuf<T> &dst, View<T> &view, const T *src, siz
     return 0;
 }
 
+
+// ---- stage functions (stages.hip), shared by the single-GPU run and the sharded flow ----
+struct ExactLocal {                  // device results of class detection over one rank's records
+    DBuf<u64> rec, trec;             // records and sort ping-pong; rec_s points at the sorted copy (flag byte in the low 8 bits)
+    DBuf<u32> gp, tgp;
+    const u64 *rec_s = nullptr;
+    const u32 *gp_s = nullptr;
+    DBuf<u32> class_start;           // [NR+1]
+    DBuf<u32> repmask;               // [n_words] representatives of this rank's classes
+    DBuf<u64> cls;                   // [NNS] rep<<32 | class index, classes with >= 2 entries
+    u64 N = 0, NR = 0, NNS = 0;
+    void release_all() { rec.release(); trec.release(); gp.release(); tgp.release(); class_start.release(); repmask.release(); cls.release(); rec_s = nullptr; gp_s = nullptr; }
+};
+struct ExactParts {                  // entry lists of classes, ent laid out in the order of cls
+    DBuf<u64> cls;
+    DBuf<u32> ce, ent;
+    DBuf<u8> edir;
+    u64 NNS = 0, NE = 0;
+    void release_all() { cls.release(); ce.release(); ent.release(); edir.release(); NNS = NE = 0; }
+};
+struct PairStore {
+    DBuf<PairRec> pairs;
+    u64 n = 0, cap = 0;
+};
+
+int st_pack(cora_hip_job *job);
+int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out);
+int st_exact_classes(cora_hip_job *job, ExactLocal &x);
+int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p);
+int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &host_ms);
+int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBuf<u32> &reps, u64 &n_out);
+int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps);
+int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
+void shard_state_free(cora_hip_job *job);

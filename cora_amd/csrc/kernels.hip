@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict_
 __global__ __launch_bounds__(256) void k_kmer_count(DevParams p, const u32 *__restrict__ bad, u32 *__restrict__ block_counts)
 {
     __shared__ u32 wsum[4];
-    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 g = p.pos_base + (u64)blockIdx.x * 256 + threadIdx.x;
     const bool ok = (g < p.G) && window_ok(p, bad, g);
     const u64 bal = __ballot(ok);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_kmer_emit(DevParams p, const u64 *__res
 {
     __shared__ u32 wsum[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 g = p.pos_base + (u64)blockIdx.x * 256 + threadIdx.x;
     const bool ok = (g < p.G) && window_ok(p, bad, g);
     const u64 bal = __ballot(ok);
     if (lane == 0) wsum[wv] = (u32)__popcll(bal);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64
 {
     __shared__ u32 wsum[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 g = p.pos_base + (u64)blockIdx.x * 256 + threadIdx.x;
     const bool ok = (g < p.G) && window_ok(p, bad, g);
     const u64 bal = __ballot(ok);
     if (lane == 0) wsum[wv] = (u32)__popcll(bal);
@@ -327,6 +327,19 @@ __global__ __launch_bounds__(256) void k_contig_check(DevParams p, const u32 *__
         if (gpos[mid] < lo_g) a = mid + 1; else b = mid;
     }
     if (a >= n || gpos[a] >= hi_g) atomicAdd(&ctr->empty_contigs, 1ull);
+}
+
+// the same check straight from the validity bitmap, one block per contig (sharded runs: no rank holds every window)
+__global__ __launch_bounds__(256) void k_contig_scan(DevParams p, const u32 *__restrict__ bad, DevCounters *ctr)
+{
+    const u32 c = blockIdx.x;
+    const u64 lo_g = p.ctg_gstart[c], len = p.ctg_len[c];
+    for (u64 base = 0; base < len; base += 256) {
+        const u64 o = base + threadIdx.x;
+        const bool ok = (o < len) && window_ok(p, bad, lo_g + o);
+        if (__syncthreads_or(ok)) return;
+    }
+    if (threadIdx.x == 0) atomicAdd(&ctr->empty_contigs, 1ull);
 }
 
 // ------------------------------------------------------------------ classes over the sorted keys
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(256) void k_bitmap_count(const u32 *__restrict__ bi
 }
 
 __global__ __launch_bounds__(256) void k_bitmap_emit(const u32 *__restrict__ bits, u64 n_words, const u64 *__restrict__ block_off,
-                                                     u32 *__restrict__ out)
+                                                     u32 *__restrict__ out, u32 base)
 {
     __shared__ u32 l4[4];
     const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(256) void k_bitmap_emit(const u32 *__restrict__ bit
     u64 at = block_off[blockIdx.x] + block_excl_scan_u32((u32)__popc(word), l4, nullptr);
     while (word) {
         const int lz = __clz((int)word);
-        out[at++] = (u32)(w * 32 + lz);
+        out[at++] = base + (u32)(w * 32 + lz);
         word &= ~(0x80000000u >> lz);
     }
 }
@@ -820,6 +833,10 @@ void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_p
 {
     hipLaunchKernelGGL(k_contig_check, grid_for(p.n_contigs), dim3(256), 0, s, p, gpos_by_position, n, ctr);
 }
+void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCounters *ctr)
+{
+    if (p.n_contigs) hipLaunchKernelGGL(k_contig_scan, dim3(p.n_contigs), dim3(256), 0, s, p, bad, ctr);
+}
 void launch_kmer_emit_hashed(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 n_blocks,
                              u64 *rec, u32 *gpos)
 {
@@ -857,9 +874,9 @@ void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block
 {
     hipLaunchKernelGGL(k_bitmap_count, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_counts);
 }
-void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out)
+void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out, u32 base)
 {
-    hipLaunchKernelGGL(k_bitmap_emit, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_off, out);
+    hipLaunchKernelGGL(k_bitmap_emit, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_off, out, base);
 }
 void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,
                        u32 *cls_flags, u32 *cls_entries)
@@ -918,4 +935,98 @@ void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const 
     if (m) hipLaunchKernelGGL(k_chain, grid_for(m), dim3(256), 0, s, p, item_key, item_meta, head_flag, node_of_excl, node_start, n_nodes, m, blen);
 }
 
+}  // namespace cora
+
+// ------------------------------------------------------------------ helpers of the staged / sharded flow
+namespace cora {
+
+// full canonical keys of a list of window positions (full-key fallback of the exact stage)
+__global__ __launch_bounds__(256) void k_keys_from_gpos(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ gpos, u64 n,
+                                                        u64 *__restrict__ hi, u64 *__restrict__ lo)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u64 h, l;
+    canonical_at(p, pk, gpos[i], h, l);
+    hi[i] = h; lo[i] = l;
+}
+
+// key[k] = (cls[k] & rep bits) | k : lets a sort by representative carry the index into the unsorted parts
+__global__ __launch_bounds__(256) void k_rekey(const u64 *__restrict__ cls, u32 n, u64 *__restrict__ key)
+{
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) key[k] = (cls[k] & 0xFFFFFFFF00000000ull) | k;
+}
+
+__global__ __launch_bounds__(256) void k_gather_parts(const u64 *__restrict__ key_sorted, u32 n, const u32 *__restrict__ ce,
+                                                      const u64 *__restrict__ eoff, u32 *__restrict__ ce_s, u64 *__restrict__ eoff_s)
+{
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const u32 idx = (u32)key_sorted[k];
+    ce_s[k] = ce[idx]; eoff_s[k] = eoff[idx];
+}
+
+// destination rank of a record: mode 0 = range of the top 32 bits (uniform hashes), mode 1 = multiplicative
+// hash of the top 32 bits (canonical seed codes are skewed towards small values)
+__global__ __launch_bounds__(256) void k_dest_keys(const u64 *__restrict__ a, u64 n, int mode, u32 world, u64 *__restrict__ dest)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32 top = (u32)(a[i] >> 32);
+    if (mode == 1) top *= 0x9E3779B1u;
+    dest[i] = ((u64)top * world) >> 32;
+}
+
+__global__ __launch_bounds__(256) void k_count_dest(const u64 *__restrict__ dest, u64 n, u32 world, unsigned long long *__restrict__ counts)
+{
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) atomicAdd(&h[(u32)dest[i] & 255u], 1u);
+    __syncthreads();
+    if (threadIdx.x < world && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+void launch_keys_from_gpos(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, u64 n, u64 *hi, u64 *lo)
+{
+    if (n) hipLaunchKernelGGL(k_keys_from_gpos, grid_for(n), dim3(256), 0, s, p, pk, gpos, n, hi, lo);
+}
+void launch_rekey(hipStream_t s, const u64 *cls, u32 n, u64 *key)
+{
+    if (n) hipLaunchKernelGGL(k_rekey, grid_for(n), dim3(256), 0, s, cls, n, key);
+}
+void launch_gather_parts(hipStream_t s, const u64 *key_sorted, u32 n, const u32 *ce, const u64 *eoff, u32 *ce_s, u64 *eoff_s)
+{
+    if (n) hipLaunchKernelGGL(k_gather_parts, grid_for(n), dim3(256), 0, s, key_sorted, n, ce, eoff, ce_s, eoff_s);
+}
+void launch_dest_keys(hipStream_t s, const u64 *a, u64 n, int mode, u32 world, u64 *dest)
+{
+    if (n) hipLaunchKernelGGL(k_dest_keys, grid_for(n), dim3(256), 0, s, a, n, mode, world, dest);
+}
+void launch_count_dest(hipStream_t s, const u64 *dest, u64 n, u32 world, unsigned long long *counts)
+{
+    if (!n) return;
+    const u64 blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_count_dest, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, s, dest, n, world, counts);
+}
+
+}  // namespace cora
+
+namespace cora {
+void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 block_lo, u32 n_blocks)
+{
+    if (!n_blocks) return;
+    DevParams q = p;
+    q.pos_base = (u64)block_lo * 256;
+    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, q, bad, block_counts);
+}
+void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 block_lo,
+                                   u32 n_blocks, u64 *rec, u32 *gpos)
+{
+    if (!n_blocks) return;
+    DevParams q = p;
+    q.pos_base = (u64)block_lo * 256;
+    hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, q, pk, bad, block_off, rec, gpos);
+}
 }  // namespace cora

@@ -21,6 +21,7 @@ struct DevParams {
     u64 image_bytes;
     u64 kmask_lo;             // keeps the top 2*(K-32) bits of the low window word
     u64 seedmask_hi[4], seedmask_lo[4];   // one bit per base (bit 62-2i of word i/32) for seed s = index+1
+    u64 pos_base;             // first position of the block range a window kernel works on (0 = whole genome)
     u32 any_windowed;         // d == 3 and some contig is compacted in 50 Mbp windows (HTS:2852-2856)
     u8 sig2[16];              // physical group of (first,last) base pair
     const u64 *ctg_gstart;    // [n_contigs+1] start of each contig in the global coordinate (last = G)
@@ -60,6 +61,7 @@ void launch_kmer_count(hipStream_t s, const DevParams &p, const u32 *bad, u32 *b
 void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
                       u32 n_blocks, u64 *key_hi, u64 *key_lo, u32 *gpos);
 void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);
+void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCounters *ctr);
 void launch_kmer_emit_hashed(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
                              u32 n_blocks, u64 *rec, u32 *gpos);
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
@@ -73,7 +75,7 @@ void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u3
 void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *repmask,
                        u64 *cls /* rep<<32 | class index */, const u64 *nons_off);
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks);
-void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out);
+void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out, u32 base);
 void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,
                        u32 *cls_flags, u32 *cls_entries);
 void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, const u64 *cls, u32 n_cls,
@@ -93,4 +95,16 @@ void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_
 void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u32 *head_flag,
                   const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, int16_t *blen);
 
+}  // namespace cora
+
+namespace cora {
+void launch_keys_from_gpos(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, u64 n, u64 *hi, u64 *lo);
+void launch_rekey(hipStream_t s, const u64 *cls, u32 n, u64 *key);
+void launch_gather_parts(hipStream_t s, const u64 *key_sorted, u32 n, const u32 *ce, const u64 *eoff, u32 *ce_s, u64 *eoff_s);
+void launch_dest_keys(hipStream_t s, const u64 *a, u64 n, int mode, u32 world, u64 *dest);
+void launch_count_dest(hipStream_t s, const u64 *dest, u64 n, u32 world, unsigned long long *counts);
+// emit hashed records / count windows of a block range [block_lo, block_hi) of 256 positions each
+void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 block_lo, u32 n_blocks);
+void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
+                                   u32 block_lo, u32 n_blocks, u64 *rec, u32 *gpos);
 }  // namespace cora

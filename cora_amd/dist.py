@@ -1,0 +1,146 @@
+"""Multi-GPU table build: one process per GPU, ``torch.distributed`` moves the records.
+
+The per-rank compute is libcora_hip.so's sharded stages (cora_amd/csrc/shard.hip); this module is the
+exchange plumbing between them: ``all_to_all_single`` of K-mer records by key-hash range, of seed records
+by code hash, a sum ``all_reduce`` of the representative bitmap (bits are disjoint, so sum = or), a min
+``all_reduce`` of the first-singleton key, and gathers to rank 0 for the two final tables.  With the
+``nccl`` backend (= RCCL over xGMI) tensors stay in HBM; with ``gloo`` (CPU rehearsal of the same code
+path, e.g. two ranks sharing one GPU) they are staged through host memory.
+
+The reference has no counterpart: it is a single process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+ST_KMERS, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH = range(1, 10)
+(SLOT_SEND_A, SLOT_SEND_C, SLOT_RECV_A, SLOT_RECV_C, SLOT_REPMASK, SLOT_X_CLS, SLOT_X_CNT, SLOT_X_ENT, SLOT_X_DIR,
+ SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR) = range(13)
+
+_DTYPE = {8: torch.int64, 4: torch.int32, 1: torch.uint8}
+NO_SINGLETON = (1 << 62)        # exchanged instead of ~0 (int64 min-reduce)
+
+
+def split_sizes(counts_matrix_row, ):
+    return [int(x) for x in counts_matrix_row]
+
+
+class Comm:
+    """The four collectives the flow needs, on device tensors, over whatever backend the group has."""
+
+    def __init__(self, device):
+        self.device = device
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.staged = self.world > 1 and dist.get_backend() != "nccl"      # gloo: through host memory
+
+    def _w(self, t):
+        return t.cpu() if self.staged else t
+
+    def exchange_counts(self, counts):
+        """counts[r] = what I send to rank r  ->  what every rank sends to me."""
+        if self.world == 1:
+            return list(counts)
+        send = self._w(torch.tensor(counts, dtype=torch.int64, device=self.device))
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)
+        return [int(x) for x in recv.tolist()]
+
+    def all_to_all(self, send, send_counts, recv_counts):
+        if self.world == 1:
+            return send
+        recv = torch.empty(sum(recv_counts), dtype=send.dtype, device="cpu" if self.staged else self.device)
+        dist.all_to_all_single(recv, self._w(send), output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+        return recv.to(self.device) if self.staged else recv
+
+    def all_reduce_sum(self, t):
+        if self.world == 1:
+            return t
+        w = self._w(t)
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        return w.to(self.device) if self.staged else w
+
+    def all_reduce_min_int(self, v):
+        if self.world == 1:
+            return v
+        w = self._w(torch.tensor([v], dtype=torch.int64, device=self.device))
+        dist.all_reduce(w, op=dist.ReduceOp.MIN)
+        return int(w.item())
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+
+class ShardedJob:
+    """Drives one sharded table build; every rank calls run(); rank 0 ends up with the tables."""
+
+    def __init__(self, job: hip.Job, comm: Comm):
+        self.job, self.comm = job, comm
+        self.lib = hip.lib()
+        self.h = job._h
+
+    # ---- slots <-> torch tensors
+    def _export(self, slot):
+        n, eb = C.c_uint64(), C.c_uint32()
+        hip._check(self.lib.cora_hip_shard_slot_info(self.h, slot, C.byref(n), C.byref(eb)))
+        t = torch.empty(n.value, dtype=_DTYPE[eb.value], device=self.comm.device)
+        hip._check(self.lib.cora_hip_shard_slot_export(self.h, slot, C.c_void_p(t.data_ptr() if n.value else 0)))
+        return t
+
+    def _import(self, slot, t):
+        t = t.contiguous()
+        torch.cuda.synchronize()
+        hip._check(self.lib.cora_hip_shard_slot_import(self.h, slot, C.c_void_p(t.data_ptr() if t.numel() else 0), t.numel()))
+
+    def _stage(self, stage, arg=0):
+        counts = (C.c_uint64 * 256)()
+        hip._check(self.lib.cora_hip_shard_stage(self.h, stage, arg, counts))
+        return [int(counts[r]) for r in range(self.comm.world)]
+
+    def _route(self, pairs, counts):
+        """pairs: [(send slot, recv slot)]; counts[r] records of each send slot go to rank r."""
+        recv_counts = self.comm.exchange_counts(counts)
+        for src, dst in pairs:
+            self._import(dst, self.comm.all_to_all(self._export(src), counts, recv_counts))
+
+    def _gather_to_root(self, pairs):
+        """Each (send slot, recv slot) may have its own length: everything goes to rank 0."""
+        for src, dst in pairs:
+            t = self._export(src)
+            counts = [t.numel()] + [0] * (self.comm.world - 1)
+            recv_counts = self.comm.exchange_counts(counts)
+            self._import(dst, self.comm.all_to_all(t, counts, recv_counts))
+
+    def run(self):
+        c, lib, h = self.comm, self.lib, self.h
+        torch.cuda.synchronize()
+        hip._check(lib.cora_hip_shard_begin(h, c.rank, c.world))
+        # exact: K-mer records to the owner of their hash range
+        self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], self._stage(ST_KMERS))
+        self._stage(ST_EXACT)
+        key = C.c_uint64()
+        hip._check(lib.cora_hip_shard_get_first_singleton(h, C.byref(key)))
+        mine = NO_SINGLETON if key.value == 0xFFFFFFFFFFFFFFFF else key.value
+        glob = c.all_reduce_min_int(mine)
+        hip._check(lib.cora_hip_shard_set_first_singleton(h, 0xFFFFFFFFFFFFFFFF if glob == NO_SINGLETON else glob))
+        self._import(SLOT_REPMASK, c.all_reduce_sum(self._export(SLOT_REPMASK)))      # disjoint bits: sum = or
+        self._stage(ST_PARTS)
+        self._gather_to_root([(SLOT_X_CLS, SLOT_RX_CLS), (SLOT_X_CNT, SLOT_RX_CNT), (SLOT_X_ENT, SLOT_RX_ENT),
+                              (SLOT_X_DIR, SLOT_RX_DIR)])
+        if c.rank == 0:
+            self._stage(ST_MERGE)
+        # inexact: seed records to the owner of their code hash, verification there
+        self._stage(ST_REPS)
+        for seed in range(1, self.job.d + 2):
+            self._route([(SLOT_SEND_A, SLOT_RECV_A)], self._stage(ST_SEED, seed))
+            self._stage(ST_VERIFY, seed)
+        self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], self._stage(ST_ITEMS))
+        if c.rank == 0:
+            self._stage(ST_FINISH)
+        torch.cuda.synchronize()

@@ -103,6 +103,27 @@ int cora_hip_job_tables(const cora_hip_job *job,
                         const uint8_t **inexact, size_t *inexact_bytes, uint64_t *inexact_nodes);
 int cora_hip_job_stats(const cora_hip_job *job, cora_hip_stats *out);
 
+/* ---- multi-GPU: one process per GPU, no counterpart in the reference (it has no distributed code) ----
+ * Every rank holds the packed reference, scans 1/R of the positions and owns 1/R of the key space.  The
+ * library computes per rank; the caller moves the "slots" between ranks with its collective library
+ * (cora_amd/dist.py: torch.distributed all_to_all_single / all_reduce over RCCL).  Stage order and the
+ * exchange after each stage are listed at the top of cora_amd/csrc/shard.hip.  All pointers handed to
+ * slot_export / slot_import are DEVICE pointers.  Restates, sharded, the same reference phases as
+ * cora_hip_job_run (HTS:2499-2800, 249-1638). */
+enum cora_hip_shard_stage_id { CORA_ST_KMERS = 1, CORA_ST_EXACT, CORA_ST_PARTS, CORA_ST_MERGE, CORA_ST_REPS,
+                               CORA_ST_SEED, CORA_ST_VERIFY, CORA_ST_ITEMS, CORA_ST_FINISH };
+enum cora_hip_shard_slot_id { CORA_SLOT_SEND_A = 0, CORA_SLOT_SEND_C, CORA_SLOT_RECV_A, CORA_SLOT_RECV_C, CORA_SLOT_REPMASK,
+                              CORA_SLOT_X_CLS, CORA_SLOT_X_CNT, CORA_SLOT_X_ENT, CORA_SLOT_X_DIR,
+                              CORA_SLOT_RX_CLS, CORA_SLOT_RX_CNT, CORA_SLOT_RX_ENT, CORA_SLOT_RX_DIR };
+int cora_hip_shard_begin(cora_hip_job *job, int rank, int world);
+/* Runs one stage; counts[world] (may be NULL) receives how many records of the SEND slots go to each rank. */
+int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint64_t *counts);
+int cora_hip_shard_slot_info(cora_hip_job *job, int slot, uint64_t *n_elems, uint32_t *elem_bytes);
+int cora_hip_shard_slot_export(cora_hip_job *job, int slot, void *dst_device);
+int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const void *src_device, uint64_t n_elems);
+int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
+int cora_hip_shard_set_first_singleton(cora_hip_job *job, uint64_t key);
+
 /* ---- stage-level entry points (used by the parity tests and the benchmark) ---- */
 
 /* Stable LSD radix sort of n records on device memory, keyed on bits

@@ -1,0 +1,33 @@
+"""One rank of the sharded flow for tests/test_gpu_sharded.py: all ranks share GPU 0 and talk through gloo."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch
+import torch.distributed as dist
+
+import helpers
+from cora_amd import dist as cdist
+from cora_amd import hip
+
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+hip.init(0)
+comm = cdist.Comm(torch.device("cuda", 0))
+for name in os.environ["CORA_TEST_CASES"].split(","):
+    c, want = helpers.golden_case(name)
+    job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
+    job.set_reference_file(helpers.input_path(c["input"]))
+    cdist.ShardedJob(job, comm).run()
+    if rank == 0:
+        e, en, i, inn = job.tables()
+        out = os.environ["CORA_TEST_OUT"]
+        open(os.path.join(out, name + ".Exact"), "wb").write(e)
+        open(os.path.join(out, name + ".Inexact"), "wb").write(i)
+    job.close()
+    comm.barrier()
+dist.destroy_process_group()
