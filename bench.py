@@ -6,9 +6,11 @@
 A step is one complete table build (2-bit pack -> canonical k-mers -> radix sort -> classes ->
 seeds -> pair verification -> block merge -> both tables as bytes) over a synthetic reference whose
 FASTA image is already resident in HBM when the timed region starts.  N=1 runs configs[1]: the
-chr20-sized (64 Mbp) synthetic contig, K=50, d=2.  For N>1 every rank builds the table of its own
-64 Mbp reference (weak scaling, no data-path collective); ranks synchronise only to time the job.
-One JSON line on rank 0."""
+chr20-sized (64 Mbp) synthetic contig, K=50, d=2.  For N>1 the ranks build ONE table pair over a reference
+of N such contigs (weak scaling: 64 Mbp per GPU): every rank holds the packed reference, scans 1/N of the
+positions and owns 1/N of the key space; records move by all-to-all over RCCL (cora_amd/dist.py) and rank 0
+ends up with both tables.  --mode replicas instead builds one independent 64 Mbp table per rank (no
+collective in the data path).  One JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -63,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bases", type=int, default=64_000_000, help="reference length (default: chr20-sized)")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="bases of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="what N>1 ranks do (see the module text)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = host-staged rehearsal)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,10 +74,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    local_rank %= max(1, torch.cuda.device_count())      # rehearsals put several ranks on one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from cora_amd import hip, synth
     K, d = 50, 2
@@ -82,10 +87,21 @@ def main():
     phys, par = os.path.join(tmp, "phys10.txt"), os.path.join(tmp, "par8.txt")
     synth.write_round_robin_splits(phys, 2, 10)      # cora's defaults: -p 10 -t 8
     synth.write_round_robin_splits(par, 4, 8)
-    contigs = synth.workload_chr20_like(20 + rank, a.bases)
+    sharded = world > 1 and a.mode == "sharded"
+    if sharded:                                     # one reference of `world` contigs, the same on every rank
+        contigs = [("chr20_like_%d" % c, synth.workload_chr20_like(20 + c, a.bases)[0][1]) for c in range(world)]
+    else:
+        contigs = synth.workload_chr20_like(20 + rank, a.bases)
     image, W, geom = synth.fasta_image(contigs, 60)
+    del contigs
     job = hip.Job(K, d, phys, par)
     job.set_reference(image, W, geom)               # H2D copy: the image is HBM-resident from here on
+    if sharded:
+        from cora_amd import dist as cdist
+        sj = cdist.ShardedJob(job, cdist.Comm(torch.device("cuda", local_rank)))
+        run = sj.run
+    else:
+        run = job.run
 
     def sync():
         torch.cuda.synchronize()
@@ -94,21 +110,22 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        job.run()
+        run()
     sync()
     t0 = time.perf_counter()
     sc_ms, sc_n, sc_bytes = 0.0, 0, 0
     for _ in range(a.steps):
-        job.run()
+        run()
         st = job.stats()
         sc_ms += st["ms_sort_scatter"]; sc_n += st["n_sort_scatter"]; sc_bytes += st["sort_scatter_bytes"]
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dev = "cuda" if a.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        kt = torch.tensor([float(st["kmers"])], device="cuda", dtype=torch.float64)
+        kt = torch.tensor([float(st["kmers"])], device=dev, dtype=torch.float64)   # sharded: the records this rank owned
         dist.all_reduce(kt, op=dist.ReduceOp.SUM)
         kmers_all = float(kt.item())
     else:
@@ -120,17 +137,21 @@ def main():
             "metric": "ref k-mers/sec into homology table (d=2)", "value": kmers_all * a.steps / dt, "unit": "k-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "chr20_like synthetic contig, %d bp per GPU, K=%d, d=%d, 60-column FASTA image resident in HBM; "
-                                   "output = both tables as bytes in host memory" % (a.bases, K, d),
-                       "kmers_per_gpu": int(st["kmers"]), "hom_pairs": int(st["hom_pairs"]), "inexact_nodes": int(st["inexact_nodes"]),
+            "config": {"workload": ("one reference of %d chr20_like synthetic contigs (%d bp each, one per GPU), K=%d, d=%d, 60-column FASTA "
+                                    "image resident in every GPU's HBM; output = both tables of the whole reference as bytes in rank 0's "
+                                    "host memory" % (world, a.bases, K, d)) if sharded else
+                                   ("chr20_like synthetic contig, %d bp per GPU, K=%d, d=%d, 60-column FASTA image resident in HBM; "
+                                    "output = both tables as bytes in host memory" % (a.bases, K, d)),
+                       "kmers_rank0": int(st["kmers"]), "hom_pairs": int(st["hom_pairs"]), "inexact_nodes": int(st["inexact_nodes"]),
                        "exact_nodes": int(st["exact_nodes"]), "hash_mixed_runs": int(st["hash_mixed_runs"]),
-                       "full_key_fallback": int(st["full_key_fallback"]), "dirty_nodes": int(st["dirty_nodes"]), "big_nodes": int(st["big_nodes"]), "parallelism": "1 reference per GPU" if world > 1 else "1 GPU"},
+                       "full_key_fallback": int(st["full_key_fallback"]), "dirty_nodes": int(st["dirty_nodes"]), "big_nodes": int(st["big_nodes"]), "parallelism": ("1 GPU" if world == 1 else "sharded: positions and key space split over %d GPUs, all-to-all over %s" % (world, a.backend)
+                                       if sharded else "replicas: 1 independent reference per GPU")},
             "stage_ms": {k: round(st[k], 3) for k in ("ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total")},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter (LSD radix scatter, all sorts of the path)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launches_per_step": sc_n // max(1, a.steps), "avg_launch_ms": sc_ms / max(1, sc_n), "traffic": None},
         }
-        cb = cpu_baseline(K, d, a.cpu_sample, tmp) if a.cpu_sample > 0 else None
+        cb = cpu_baseline(K, d, a.cpu_sample, tmp) if (a.cpu_sample > 0 and world == 1) else None
         out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     job.close()

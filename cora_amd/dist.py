@@ -26,25 +26,23 @@ _DTYPE = {8: torch.int64, 4: torch.int32, 1: torch.uint8}
 NO_SINGLETON = (1 << 62)        # exchanged instead of ~0 (int64 min-reduce)
 
 
-def split_sizes(counts_matrix_row, ):
-    return [int(x) for x in counts_matrix_row]
-
-
 class Comm:
     """The four collectives the flow needs, on device tensors, over whatever backend the group has."""
 
-    def __init__(self, device):
+    def __init__(self, device, always_collective=False):
         self.device = device
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.staged = self.world > 1 and dist.get_backend() != "nccl"      # gloo: through host memory
+        # world 1 skips the collectives unless asked not to (a test drives RCCL with a single rank that way)
+        self.local = self.world == 1 and not (always_collective and dist.is_initialized())
+        self.staged = dist.is_initialized() and dist.get_backend() != "nccl"      # gloo: through host memory
 
     def _w(self, t):
         return t.cpu() if self.staged else t
 
     def exchange_counts(self, counts):
         """counts[r] = what I send to rank r  ->  what every rank sends to me."""
-        if self.world == 1:
+        if self.local:
             return list(counts)
         send = self._w(torch.tensor(counts, dtype=torch.int64, device=self.device))
         recv = torch.empty_like(send)
@@ -52,28 +50,28 @@ class Comm:
         return [int(x) for x in recv.tolist()]
 
     def all_to_all(self, send, send_counts, recv_counts):
-        if self.world == 1:
+        if self.local:
             return send
         recv = torch.empty(sum(recv_counts), dtype=send.dtype, device="cpu" if self.staged else self.device)
         dist.all_to_all_single(recv, self._w(send), output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
         return recv.to(self.device) if self.staged else recv
 
     def all_reduce_sum(self, t):
-        if self.world == 1:
+        if self.local:
             return t
         w = self._w(t)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         return w.to(self.device) if self.staged else w
 
     def all_reduce_min_int(self, v):
-        if self.world == 1:
+        if self.local:
             return v
         w = self._w(torch.tensor([v], dtype=torch.int64, device=self.device))
         dist.all_reduce(w, op=dist.ReduceOp.MIN)
         return int(w.item())
 
     def barrier(self):
-        if self.world > 1:
+        if not self.local:
             dist.barrier()
 
 

@@ -14,10 +14,10 @@ from cora_amd import dist as cdist
 from cora_amd import hip
 
 rank, world = int(sys.argv[1]), int(sys.argv[2])
-dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.cuda.set_device(0)
+dist.init_process_group(os.environ.get("CORA_TEST_BACKEND", "gloo"), rank=rank, world_size=world)
 hip.init(0)
-comm = cdist.Comm(torch.device("cuda", 0))
+comm = cdist.Comm(torch.device("cuda", 0), always_collective=True)
 for name in os.environ["CORA_TEST_CASES"].split(","):
     c, want = helpers.golden_case(name)
     job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))

@@ -43,3 +43,17 @@ def test_sharded_ranks_over_gloo_equal_reference(world, tmp_path):
         c, want = helpers.golden_case(name)
         assert helpers.read(os.path.join(str(tmp_path), name + ".Exact")) == helpers.read(os.path.join(want, "Exact")), name
         assert helpers.read(os.path.join(str(tmp_path), name + ".Inexact")) == helpers.read(os.path.join(want, "Inexact")), name
+
+
+def test_rccl_collectives_single_rank():
+    """The exchange calls exactly as the N > 1 bench makes them (nccl backend = RCCL, device tensors, uneven
+    all_to_all_single of int64 / int32 / uint8, int32 sum, int64 min), with the only world size one GPU allows."""
+    script = os.path.join(helpers.ROOT, "tests", "support", "sharded_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", CORA_TEST_CASES="q_k50_d2_p10,fam_k48_d3",
+               CORA_TEST_OUT=helpers.scratch(), CORA_TEST_BACKEND="nccl")
+    p = subprocess.run([sys.executable, script, "0", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-3000:]
+    for name in ("q_k50_d2_p10", "fam_k48_d3"):
+        c, want = helpers.golden_case(name)
+        assert helpers.read(os.path.join(env["CORA_TEST_OUT"], name + ".Exact")) == helpers.read(os.path.join(want, "Exact")), name
+        assert helpers.read(os.path.join(env["CORA_TEST_OUT"], name + ".Inexact")) == helpers.read(os.path.join(want, "Inexact")), name
