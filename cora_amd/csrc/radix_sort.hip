@@ -8,6 +8,7 @@
 //   rs_scatter   rank in LDS, stage, write                     (reads + writes every array)
 // HBM traffic per pass and record: 8 B (hist) + 2 x record bytes (scatter).
 #include "radix_sort.hpp"
+#include <stdlib.h>
 
 namespace cora {
 
@@ -41,47 +42,114 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist(const u64 *__restrict__ w,
     h[tid] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * RS_TILE;
+    if (base + RS_TILE <= n && ((size_t)w & 15) == 0) { // whole tile: 16-byte loads, two records each (order is irrelevant here)
+        const ulonglong2 *w2 = reinterpret_cast<const ulonglong2 *>(w + base);
+        ulonglong2 v[RS_IPT / 2];
 #pragma unroll
-    for (int k = 0; k < RS_IPT; k++) {
-        u64 idx = base + (u64)k * RS_THREADS + tid;
-        if (idx < n) atomicAdd(&h[(u32)(w[idx] >> shift) & mask], 1u);
+        for (int k = 0; k < RS_IPT / 2; k++) v[k] = w2[k * RS_THREADS + tid];
+#pragma unroll
+        for (int k = 0; k < RS_IPT / 2; k++) {
+            atomicAdd(&h[(u32)(v[k].x >> shift) & mask], 1u);
+            atomicAdd(&h[(u32)(v[k].y >> shift) & mask], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RS_IPT; k++) {
+            u64 idx = base + (u64)k * RS_THREADS + tid;
+            if (idx < n) atomicAdd(&h[(u32)(w[idx] >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     tile_hist[(size_t)blockIdx.x * 256 + tid] = h[tid];
 }
+
+// Offsets: the run of digit d of tile t starts at  sum of all counts of digits < d  +  counts of d in tiles < t.
+//   rs_colsum    per chunk of RS_CHUNK_TILES tiles: count of every digit               [chunks][256]
+//   rs_chunkscan one workgroup: per digit, exclusive scan over the chunks + the digit's base
+//   rs_colscan   per chunk: walk its tiles, turning counts into offsets
+// Loads are issued in batches of independent loads before anything is stored: these kernels are latency-bound.
+constexpr int RS_BATCH = 16;
 
 __global__ __launch_bounds__(256) void rs_colsum(const u32 *__restrict__ tile_hist, u32 tiles, u32 *__restrict__ chunk_sums)
 {
     const u32 t0 = blockIdx.x * RS_CHUNK_TILES;
     const u32 t1 = min(tiles, t0 + RS_CHUNK_TILES);
     u32 s = 0;
-    for (u32 t = t0; t < t1; t++) s += tile_hist[(size_t)t * 256 + threadIdx.x];
+    for (u32 t = t0; t < t1; t += RS_BATCH) {
+        u32 v[RS_BATCH];
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) v[i] = (t + i < t1) ? tile_hist[(size_t)(t + i) * 256 + threadIdx.x] : 0;
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) s += v[i];
+    }
     chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void rs_chunkscan(u32 *__restrict__ chunk_sums, u32 chunks)
+// 1024 threads: thread (q, d) scans quarter q of the chunks for digit d; chunk_off[c][d] = digit base + counts in chunks < c
+__global__ __launch_bounds__(1024) void rs_chunkscan(const u32 *__restrict__ chunk_sums, u32 *__restrict__ chunk_off, u32 chunks)
 {
+    __shared__ u32 qsum[4][256];
     __shared__ u32 wsum[4];
-    const int d = threadIdx.x;
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const u32 per = (chunks + 3) / 4;
+    const u32 c0 = min(chunks, q * per), c1 = min(chunks, c0 + per);
     u32 run = 0;
-    for (u32 c = 0; c < chunks; c++) {
-        u32 v = chunk_sums[(size_t)c * 256 + d];
-        chunk_sums[(size_t)c * 256 + d] = run;
-        run += v;
+    for (u32 c = c0; c < c1; c += RS_BATCH) {
+        u32 v[RS_BATCH];
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) v[i] = (c + i < c1) ? chunk_sums[(size_t)(c + i) * 256 + d] : 0;
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) run += v[i];
     }
-    u32 base = block_exclusive_scan_256(run, wsum, nullptr);
-    for (u32 c = 0; c < chunks; c++) chunk_sums[(size_t)c * 256 + d] += base;
+    qsum[q][d] = run;
+    __syncthreads();
+    u32 base = 0;
+    if (q == 0) {                                    // (threads 0..255: exactly the shape block_exclusive_scan_256 expects)
+        const u32 tot = qsum[0][d] + qsum[1][d] + qsum[2][d] + qsum[3][d];
+        const int lane = d & 63, wv = d >> 6;
+        u32 x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            u32 y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        base = x - tot;
+    }
+    __syncthreads();
+    if (q == 0) {
+        for (int w = 0; w < (d >> 6); w++) base += wsum[w];
+        const u32 q0 = qsum[0][d], q1 = qsum[1][d], q2 = qsum[2][d];
+        qsum[0][d] = base; qsum[1][d] = base + q0; qsum[2][d] = base + q0 + q1; qsum[3][d] = base + q0 + q1 + q2;
+    }
+    __syncthreads();
+    run = qsum[q][d];
+    for (u32 c = c0; c < c1; c += RS_BATCH) {
+        u32 v[RS_BATCH];
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) v[i] = (c + i < c1) ? chunk_sums[(size_t)(c + i) * 256 + d] : 0;
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) {
+            if (c + i < c1) chunk_off[(size_t)(c + i) * 256 + d] = run;
+            run += v[i];
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void rs_colscan(u32 *__restrict__ tile_hist, u32 tiles, const u32 *__restrict__ chunk_sums)
+__global__ __launch_bounds__(256) void rs_colscan(u32 *tile_hist, u32 tiles, const u32 *__restrict__ chunk_off)
 {
     const u32 t0 = blockIdx.x * RS_CHUNK_TILES;
     const u32 t1 = min(tiles, t0 + RS_CHUNK_TILES);
-    u32 run = chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x];
-    for (u32 t = t0; t < t1; t++) {
-        u32 v = tile_hist[(size_t)t * 256 + threadIdx.x];
-        tile_hist[(size_t)t * 256 + threadIdx.x] = run;
-        run += v;
+    u32 run = chunk_off[(size_t)blockIdx.x * 256 + threadIdx.x];
+    for (u32 t = t0; t < t1; t += RS_BATCH) {
+        u32 v[RS_BATCH];
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) v[i] = (t + i < t1) ? tile_hist[(size_t)(t + i) * 256 + threadIdx.x] : 0;
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; i++) {
+            if (t + i < t1) tile_hist[(size_t)(t + i) * 256 + threadIdx.x] = run;
+            run += v[i];
+        }
     }
 }
 
@@ -92,14 +160,23 @@ template <bool HAS_B, bool HAS_C, bool DIG_B>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__ a_in, const u64 *__restrict__ b_in,
                                                           const u32 *__restrict__ c_in, u64 *__restrict__ a_out,
                                                           u64 *__restrict__ b_out, u32 *__restrict__ c_out, u64 n,
-                                                          int shift, u32 mask, const u32 *__restrict__ tile_off)
+                                                          int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg)
 {
     __shared__ u64 stage[RS_TILE];          // 32 KiB
     __shared__ u32 wcnt[4][256];            // per-wave digit counters, then per-wave digit bases
     __shared__ u32 delta[256];              // global offset of the digit's run minus its local start
     __shared__ u32 wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u64 base = (u64)blockIdx.x * RS_TILE;
+    // The 8 XCDs have separate L2s and workgroups are dealt round-robin over them (b % 8).  The output runs of
+    // neighbouring tiles meet inside cache lines; when the neighbours run on different XCDs both L2s write their
+    // part of such a line back as a partial write (measured: 20-30 % of the scatter bandwidth).  So every XCD
+    // gets runs of xg consecutive tiles.  Placement is a speed matter only: any mapping is a permutation.
+    u32 tile = blockIdx.x;
+    if (xg > 1) {
+        const u32 W = 8 * xg, w = tile / W, r = tile % W;
+        if ((w + 1) * W <= gridDim.x) tile = w * W + (r % 8) * xg + r / 8;
+    }
+    const u64 base = (u64)tile * RS_TILE;
     const u32 count = (u32)min((u64)RS_TILE, n - base);
     const u64 *dig_in = DIG_B ? b_in : a_in;
     const u64 *oth_in = DIG_B ? a_in : b_in;
@@ -112,6 +189,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__
     for (int r = 0; r < RS_IPT; r++) {
         u32 li = l0 + r * 64;
         kw[r] = (li < count) ? dig_in[base + li] : 0;
+    }
+    u32 cv[HAS_C ? RS_IPT : 1];             // the payload is fetched now, beside the keys, and staged after them
+    if (HAS_C) {
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) {
+            u32 li = l0 + r * 64;
+            cv[r] = (li < count) ? c_in[base + li] : 0;
+        }
     }
 #pragma unroll
     for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
@@ -144,7 +229,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__
         const u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
         const u32 start = block_exclusive_scan_256(c0 + c1 + c2 + c3, wsum, nullptr);
         wcnt[0][tid] = start; wcnt[1][tid] = start + c0; wcnt[2][tid] = start + c0 + c1; wcnt[3][tid] = start + c0 + c1 + c2;
-        delta[tid] = tile_off[(size_t)blockIdx.x * 256 + tid] - start;
+        delta[tid] = tile_off[(size_t)tile * 256 + tid] - start;
     }
     __syncthreads();
 #pragma unroll
@@ -186,7 +271,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            if (li < count) stage32[lpos[r]] = c_in[base + li];
+            if (li < count) stage32[lpos[r]] = cv[r];
         }
         __syncthreads();
 #pragma unroll
@@ -210,10 +295,15 @@ int SortScratch::reserve(u64 n)
     if (chunks > cap_chunks) {
         if (chunk_sums) (void)hipFree(chunk_sums);
         chunk_sums = nullptr; cap_chunks = 0;
-        RS_CHECK(hipMalloc(&chunk_sums, chunks * 256 * sizeof(u32)));
+        RS_CHECK(hipMalloc(&chunk_sums, 2 * chunks * 256 * sizeof(u32)));     // sums, then offsets
         cap_chunks = chunks;
     }
-    if (!ev0) { RS_CHECK(hipEventCreate(&ev0)); RS_CHECK(hipEventCreate(&ev1)); }
+    if (!ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&ev[i]));
+    if (!xcd_group) {
+        xcd_group = 16;
+        if (getenv("RS_XCD_GROUP")) xcd_group = (u32)atoi(getenv("RS_XCD_GROUP"));
+        if (!xcd_group) xcd_group = 1;
+    }
     return 0;
 }
 
@@ -221,20 +311,20 @@ void SortScratch::release()
 {
     if (tile_hist) (void)hipFree(tile_hist);
     if (chunk_sums) (void)hipFree(chunk_sums);
-    if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
-    tile_hist = nullptr; chunk_sums = nullptr; cap_tiles = cap_chunks = 0; ev0 = ev1 = nullptr;
+    if (ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+    tile_hist = nullptr; chunk_sums = nullptr; cap_tiles = cap_chunks = 0;
 }
 
 template <bool HAS_B, bool HAS_C>
 static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
-                           int shift, u32 mask, const u32 *tile_off)
+                           int shift, u32 mask, const u32 *tile_off, u32 xg)
 {
     if (HAS_B && dig_b)
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true>), dim3(tiles), dim3(RS_THREADS), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off);
+                           out.c, n, shift, mask, tile_off, xg);
     else
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false>), dim3(tiles), dim3(RS_THREADS), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off);
+                           out.c, n, shift, mask, tile_off, xg);
 }
 
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi, SortScratch &scratch,
@@ -243,13 +333,16 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     if (n == 0 || bit_hi <= bit_lo) return 0;
     if (n >= (1ull << 32)) return (int)hipErrorInvalidValue;      // u32 offsets inside the kernels
     bit_lo &= ~7;
+    if ((bit_hi - bit_lo + 7) / 8 > RS_MAX_PASSES) return (int)hipErrorInvalidValue;
+    const bool timed = timing && timing->enabled;
+    int pass = 0;
     int rc = scratch.reserve(n);
     if (rc) return rc;
     const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
     const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
     const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
     const u64 rec_bytes = 8 + (has_b ? 8 : 0) + (has_c ? 4 : 0);
-    for (int bit = bit_lo; bit < bit_hi; bit += 8) {
+    for (int bit = bit_lo; bit < bit_hi; bit += 8, pass++) {
         const int nbits = (bit_hi - bit) < 8 ? (bit_hi - bit) : 8;
         const u32 mask = (1u << nbits) - 1u;
         const bool dig_b = has_b && bit < 64;
@@ -257,26 +350,29 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const u64 *word = dig_b ? keys.b : keys.a;
         hipLaunchKernelGGL(rs_hist, dim3(tiles), dim3(RS_THREADS), 0, s, word, n, shift, mask, scratch.tile_hist);
         hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, scratch.chunk_sums);
-        hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(256), 0, s, scratch.chunk_sums, chunks);
-        hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, scratch.chunk_sums);
-        if (timing && timing->enabled) RS_CHECK(hipEventRecord(scratch.ev0, s));
+        u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
+        hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);
+        hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, chunk_off);
+        if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass], s));
         if (has_b) {
-            if (has_c) launch_scatter<true, true>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
-            else launch_scatter<true, false>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
+            if (has_c) launch_scatter<true, true>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
+            else launch_scatter<true, false>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
         } else {
-            if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
-            else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist);
+            if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
+            else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
         }
-        if (timing && timing->enabled) {
-            RS_CHECK(hipEventRecord(scratch.ev1, s));
-            RS_CHECK(hipEventSynchronize(scratch.ev1));
+        if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass + 1], s));
+        SortArrays t = keys; keys = tmp; tmp = t;
+    }
+    if (timed) {                                                   // read the events once, after the last pass
+        RS_CHECK(hipEventSynchronize(scratch.ev[2 * pass - 1]));
+        for (int q = 0; q < pass; q++) {
             float ms = 0.f;
-            RS_CHECK(hipEventElapsedTime(&ms, scratch.ev0, scratch.ev1));
+            RS_CHECK(hipEventElapsedTime(&ms, scratch.ev[2 * q], scratch.ev[2 * q + 1]));
             timing->scatter_ms += ms;
             timing->scatter_launches += 1;
             timing->scatter_bytes += 2 * rec_bytes * n;
         }
-        SortArrays t = keys; keys = tmp; tmp = t;
     }
     RS_CHECK(hipGetLastError());
     return 0;

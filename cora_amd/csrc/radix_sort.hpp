@@ -30,15 +30,17 @@ struct SortScratch {
     u32 *tile_hist = nullptr;    // [tiles][256]
     u32 *chunk_sums = nullptr;   // [chunks][256]
     size_t cap_tiles = 0, cap_chunks = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    u32 xcd_group = 0;           // consecutive tiles handed to one XCD by the scatter (0 = not chosen yet)
+    hipEvent_t ev[2 * 16] = {};  // one pair per pass of a sort
     int reserve(u64 n);
     void release();
 };
 
+constexpr int RS_MAX_PASSES = 16;
 constexpr int RS_THREADS = 256;
 constexpr int RS_IPT = 16;
 constexpr int RS_TILE = RS_THREADS * RS_IPT;      // 4096 records per workgroup
-constexpr int RS_CHUNK_TILES = 128;               // tiles per column-scan workgroup
+constexpr int RS_CHUNK_TILES = 64;                // tiles per column-scan workgroup
 
 // Sorts n records by key bits [bit_lo, bit_hi) (bit 0 = LSB of the logical key,
 // bit_lo is rounded down to a multiple of 8).  Stable.  `keys` and `tmp` are
