@@ -166,7 +166,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     {
         RCQ(st_exact_classes(job, x));
         st.representatives = x.NR; st.exact_classes = x.NNS;
-        RCQ(st_reps(job, x.repmask.p, 0, dp.n_words, reps, NR));
+        launch_rep_mask(s, dp, job->bad.p, x.nonrep.p, x.nonrep.p);        // in place: now the representative bitmap
+        RCQ(st_reps(job, x.nonrep.p, 0, dp.n_words, reps, NR));
         ExactParts parts;
         RCQ(st_exact_parts(job, x, parts));
         x.release_all();

@@ -189,10 +189,10 @@ struct ExactLocal {                  // device results of class detection over o
     const u64 *rec_s = nullptr;
     const u32 *gp_s = nullptr;
     DBuf<u32> class_start;           // [NR+1]
-    DBuf<u32> repmask;               // [n_words] representatives of this rank's classes
+    DBuf<u32> nonrep;                // [n_words] later members of this rank's classes (every valid window not in here is a representative)
     DBuf<u64> cls;                   // [NNS] rep<<32 | class index, classes with >= 2 entries
     u64 N = 0, NR = 0, NNS = 0;
-    void release_all() { rec.release(); trec.release(); gp.release(); tgp.release(); class_start.release(); repmask.release(); cls.release(); rec_s = nullptr; gp_s = nullptr; }
+    void release_all() { rec.release(); trec.release(); gp.release(); tgp.release(); class_start.release(); nonrep.release(); cls.release(); rec_s = nullptr; gp_s = nullptr; }
 };
 struct ExactParts {                  // entry lists of classes, ent laid out in the order of cls
     DBuf<u64> cls;

@@ -413,10 +413,35 @@ __global__ __launch_bounds__(256) void k_min_u64(const unsigned long long *__res
     }
 }
 
-// Marks every class's representative (its first = lowest position, HTS:2573-2578) in the position bitmap
-// and lists the classes with >= 2 entries as rep<<32 | class index, at offsets from the scan of blk_nons.
+// Representatives = first (lowest) position of every class (HTS:2573-2578) = every valid window that is not a
+// later member of a class.  Later members are few (the repeated K-mers), so they are what gets marked, by
+// atomics, in a zeroed bitmap; k_rep_mask then turns "valid and not marked" into the representative bitmap.
+// (Marking the representatives themselves cost one scattered atomic per distinct K-mer: 2.4 ms per 64 Mbp.)
+__global__ __launch_bounds__(256) void k_nonrep_mark(const u32 *__restrict__ head_flag, const u32 *__restrict__ gpos, u64 n,
+                                                     u32 *__restrict__ nonrep)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || head_flag[i]) return;
+    const u32 g = gpos[i];
+    atomicOr(&nonrep[g >> 5], 1u << (31 - (g & 31)));
+}
+
+// rep[w] = valid windows of positions 32w..32w+31 (bit 31-i = position 32w+i) minus nonrep[w]; rep may alias nonrep
+__global__ __launch_bounds__(256) void k_rep_mask(DevParams p, const u32 *__restrict__ bad, const u32 *nonrep, u32 *rep)
+{
+    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = (g < p.G) && window_ok(p, bad, g);
+    const u64 bal = __ballot(ok);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 || lane == 32) {
+        const u64 w = g >> 5;
+        if (w < p.n_words) rep[w] = __brev((u32)(bal >> lane)) & ~nonrep[w];
+    }
+}
+
+// Lists the classes with >= 2 entries as rep<<32 | class index, at offsets from the scan of blk_nons.
 __global__ __launch_bounds__(256) void k_class_emit(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
-                                                    const u32 *__restrict__ class_start, u32 n_cls, u32 *__restrict__ repmask,
+                                                    const u32 *__restrict__ class_start, u32 n_cls,
                                                     u64 *__restrict__ cls, const u64 *__restrict__ nons_off)
 {
     __shared__ u32 s_nons[4];
@@ -427,7 +452,6 @@ __global__ __launch_bounds__(256) void k_class_emit(const u64 *__restrict__ rec,
     if (c < n_cls) {
         const u32 st = class_start[c], m = class_start[c + 1] - st;
         g = gpos[st];
-        atomicOr(&repmask[g >> 5], 1u << (31 - (g & 31)));
         nons = !(m == 1 && !((u32)rec[st] & 2u));
     }
     const u64 bn = __ballot(nons);
@@ -865,10 +889,18 @@ void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u3
     hipLaunchKernelGGL(k_class_count, g, dim3(256), 0, s, rec, gpos, class_start, n_cls, blk_nons, blk_min);
     hipLaunchKernelGGL(k_min_u64, dim3(g.x < 64 ? g.x : 64), dim3(256), 0, s, blk_min, (u64)g.x, &ctr->first_singleton_key);
 }
-void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *repmask, u64 *cls,
+void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u64 *cls,
                        const u64 *nons_off)
 {
-    if (n_cls) hipLaunchKernelGGL(k_class_emit, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, n_cls, repmask, cls, nons_off);
+    if (n_cls) hipLaunchKernelGGL(k_class_emit, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, n_cls, cls, nons_off);
+}
+void launch_nonrep_mark(hipStream_t s, const u32 *head_flag, const u32 *gpos, u64 n, u32 *nonrep)
+{
+    if (n) hipLaunchKernelGGL(k_nonrep_mark, grid_for(n), dim3(256), 0, s, head_flag, gpos, n, nonrep);
+}
+void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep)
+{
+    hipLaunchKernelGGL(k_rep_mask, grid_for(p.G), dim3(256), 0, s, p, bad, nonrep, rep);
 }
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks)
 {

@@ -3,7 +3,7 @@
 // "slots" between ranks (torch.distributed all_to_all_single / all_reduce over RCCL: cora_amd/dist.py).
 //
 //   KMERS      own position slice -> hashed K-mer records, partitioned by hash range        [all-to-all]
-//   EXACT      received records  -> sort, classes, representatives of the owned keys         [all-reduce of the
+//   EXACT      received records  -> sort, classes, later members of the owned classes        [all-reduce of that
 //                                                                       position bitmap and of the first singleton]
 //   PARTS      entry lists of the owned classes with >= 2 entries                            [gather to rank 0]
 //   MERGE      rank 0: all classes by representative, block merge, <Exact> bytes
@@ -200,7 +200,7 @@ static int slot_ref(ShardState &sh, const DevParams &dp, int slot, void **p, u64
     case SLOT_SEND_C: *p = sh.send_c.p; *n = sh.n_send; *eb = 4; return 0;
     case SLOT_RECV_A: *p = sh.recv_a.p; *n = sh.n_recv; *eb = 8; return 0;
     case SLOT_RECV_C: *p = sh.recv_c.p; *n = sh.n_recv; *eb = 4; return 0;
-    case SLOT_REPMASK: *p = sh.x.repmask.p; *n = dp.n_words; *eb = 4; return 0;
+    case SLOT_REPMASK: *p = sh.x.nonrep.p; *n = dp.n_words; *eb = 4; return 0;
     case SLOT_X_CLS: *p = sh.parts.cls.p; *n = sh.parts.NNS; *eb = 8; return 0;
     case SLOT_X_CNT: *p = sh.parts.ce.p; *n = sh.parts.NNS; *eb = 4; return 0;
     case SLOT_X_ENT: *p = sh.parts.ent.p; *n = sh.parts.NE; *eb = 4; return 0;
@@ -254,6 +254,8 @@ extern "C" int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const voi
         if (!src_device) return fail(19, "null source");
         HIPQ(hipMemcpyAsync(dst, src_device, n * eb, hipMemcpyDeviceToDevice, s));
     }
+    if (slot == SLOT_REPMASK)       // what arrives is the union of all ranks' non-representatives: turn it into the representative bitmap
+        launch_rep_mask(s, job->dp, job->bad.p, sh.repmask_g.p, sh.repmask_g.p);
     HIPQ(hipStreamSynchronize(s));
     return 0;
 }

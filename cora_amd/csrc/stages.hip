@@ -40,7 +40,7 @@ int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf
     return 0;
 }
 
-// Sort the records, group equal canonical K-mers exactly, mark representatives, list the classes with >= 2
+// Sort the records, group equal canonical K-mers exactly, mark the non-representatives, list the classes with >= 2
 // entries and find the first singleton (HTS:2516-2578).  x.rec / x.gp hold x.N records in which equal K-mers
 // appear in increasing position.
 int st_exact_classes(cora_hip_job *job, ExactLocal &x)
@@ -91,6 +91,10 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
         HIPQ(hipStreamSynchronize(s));
         x.rec_s = rec_out; x.gp_s = fk.c;
     }
+    // later members of classes = the positions that are NOT representatives
+    RCQ(x.nonrep.alloc(dp.n_words));
+    HIPQ(hipMemsetAsync(x.nonrep.p, 0, dp.n_words * sizeof(u32), s));
+    launch_nonrep_mark(s, head_flag.p, x.gp_s, N, x.nonrep.p);
     // class index of every record, class starts
     DBuf<u64> cid, scr0, tot0;
     RCQ(cid.alloc(N)); RCQ(scr0.alloc(scan_scratch_elems(N))); RCQ(tot0.alloc(1));
@@ -112,9 +116,8 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     if (exclusive_scan_u32_to_u64(s, blk_nons.p, nons_off.p, kb, scr2.p, tots.p)) return fail(100, "scan launch failed");
     HIPQ(hipMemcpyAsync(&x.NNS, tots.p, sizeof x.NNS, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
-    RCQ(x.repmask.alloc(dp.n_words)); RCQ(x.cls.alloc(x.NNS));
-    HIPQ(hipMemsetAsync(x.repmask.p, 0, dp.n_words * sizeof(u32), s));
-    launch_class_emit(s, x.rec_s, x.gp_s, x.class_start.p, (u32)x.NR, x.repmask.p, x.cls.p, nons_off.p);
+    RCQ(x.cls.alloc(x.NNS));
+    launch_class_emit(s, x.rec_s, x.gp_s, x.class_start.p, (u32)x.NR, x.cls.p, nons_off.p);
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
     return 0;

@@ -63,6 +63,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError("%s is missing: build it with `make -C cora_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        # PyTorch ships its own HIP/HSA runtime libraries.  If it is imported AFTER this library has pulled in
+        # /opt/rocm's, its runtime binds to the wrong HSA and reports "No HIP GPUs are available" (seen when the
+        # sharded driver, which moves records with torch.distributed, ran after plain table builds in one
+        # process).  Loading torch's libraries first is harmless for callers that never use it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.cora_hip_last_error.restype = C.c_char_p
         L.cora_hip_job_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
