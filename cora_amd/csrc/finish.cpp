@@ -166,8 +166,9 @@ void emit_item(Writer &w, const HostGenome &g, int d, uint32_t tgt, uint32_t dir
 // items by decreasing block length through std::sort (HTS:1368; unstable above 16 items, which is why the
 // very same library routine is applied to the very same pre-order here).
 static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResult &r, const View<uint64_t> &packed,
-                                    size_t node_begin, size_t node_end, ByteBuf &out, FinishStats &st)
+                                    size_t node_begin, size_t node_end, ByteBuf &out, FinishStats &st, size_t *marks)
 {
+    // marks[nd - node_begin] = offset in `out` where list nd's bytes start (lists are written in order)
     const int cw = g.chr_short ? 2 : 1;
     const size_t n_items = (size_t)r.node_start[node_end] - r.node_start[node_begin];
     out.reserve_uninit(n_items * (size_t)(1 + cw + 4 + g.d + 2) + (node_end - node_begin) * (size_t)(cw + 5) + 16);
@@ -198,6 +199,7 @@ static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResu
         if (!dirty) {
             for (size_t nd = i; nd < j; nd++) {
                 const uint32_t a = r.node_start[nd], b = r.node_start[nd + 1];
+                if (marks) marks[nd - node_begin] = (size_t)(w.at - out.p);
                 if (b - a == 1) {                                    // the common case: one item, nothing to order
                     if (r.blen[a] != -1) {
                         const uint32_t sp = src_of(nd), m = r.meta[a];
@@ -259,6 +261,9 @@ static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResu
             for (size_t dist = 1; k + dist < nl; dist++) {                                                        // HTS:1203-1270
                 std::vector<DItem> &comp = L[k + dist];
                 int last = 0;
+                bool live = false;                         // an item can only grow past dist if it reached dist: else nothing is left to do
+                for (const DItem &b : base) if (b.blen == (int)dist) { live = true; break; }
+                if (!live) break;
                 for (DItem &b : base) {
                     if (b.blen != (int)dist) continue;
                     const uint32_t tc = g.contig_of(b.tgt);
@@ -273,6 +278,7 @@ static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResu
                 }
             }
             std::sort(base.begin(), base.end(), [](const DItem &x, const DItem &y) { return x.blen > y.blen; });  // HTS:1368
+            if (marks) marks[i + k - node_begin] = (size_t)(w.at - out.p);
             bool header = false;
             for (const DItem &b : base) {
                 if (b.blen == -1) continue;
@@ -287,8 +293,9 @@ static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResu
 }
 
 void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
-                       ByteBuf &out, FinishStats &st, int n_threads)
+                       ByteBuf &out, FinishStats &st, int n_threads, std::vector<size_t> *marks)
 {
+    if (marks) marks->assign(r.node_start.empty() ? 1 : r.node_start.size(), 0);
     const size_t n_nodes = r.node_start.empty() ? 0 : r.node_start.size() - 1;
     st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
     out.n = 0;
@@ -319,12 +326,13 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
     std::vector<FinishStats> sts(parts);
     std::vector<std::thread> th;
     for (size_t k = 1; k < parts; k++)
-        th.emplace_back([&, k]() { serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k]); });
-    serialize_inexact_range(g, r, packed, cut[0], cut[1], bufs[0], sts[0]);
+        th.emplace_back([&, k]() { serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k], marks ? marks->data() + cut[k] : nullptr); });
+    serialize_inexact_range(g, r, packed, cut[0], cut[1], bufs[0], sts[0], marks ? marks->data() + cut[0] : nullptr);
     for (auto &x : th) x.join();
     std::vector<size_t> off(parts + 1, 0);
     for (size_t k = 0; k < parts; k++) {
         off[k + 1] = off[k] + bufs[k].size();
+        if (marks) for (size_t nd = cut[k]; nd < cut[k + 1]; nd++) (*marks)[nd] += off[k];
         st.inexact_nodes += sts[k].inexact_nodes; st.dirty_nodes += sts[k].dirty_nodes; st.big_nodes += sts[k].big_nodes;
     }
     out.reserve_uninit(off[parts] + 16);
@@ -333,6 +341,44 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
     for (size_t k = 1; k < parts; k++)
         th.emplace_back([&, k]() { if (bufs[k].size()) memcpy(out.p + off[k], bufs[k].data(), bufs[k].size()); });
     if (bufs[0].size()) memcpy(out.p, bufs[0].data(), bufs[0].size());
+    for (auto &x : th) x.join();
+    if (marks) (*marks)[n_nodes] = off[parts];
+}
+
+// The device wrote the bytes of its lists back to back (`stream`); the host lists (in list order, each with the
+// stream offset its bytes belong at) are finished here and spliced in.
+void assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
+                      View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads)
+{
+    ByteBuf hb;
+    std::vector<size_t> marks;
+    FinishStats hst;
+    if (hnodes.size()) serialize_inexact(g, host_items, packed, hb, hst, n_threads, &marks);
+    st.inexact_nodes = device_nodes + hst.inexact_nodes;
+    st.dirty_nodes = hst.dirty_nodes; st.big_nodes = hst.big_nodes;
+    const size_t total = stream.size() + hb.size();
+    out.reserve_uninit(total + 16);
+    out.n = total;
+    struct Piece { const uint8_t *src; size_t dst, n; };
+    std::vector<Piece> pieces;
+    const size_t chunk = 1u << 18;
+    auto add = [&](const uint8_t *src, size_t dst, size_t n) {
+        for (size_t o = 0; o < n; o += chunk) pieces.push_back({src + o, dst + o, std::min(chunk, n - o)});
+    };
+    size_t s_at = 0, d_at = 0;
+    for (size_t i = 0; i < hnodes.size(); i++) {
+        const size_t so = (size_t)hnodes[i].stream_off;
+        if (so > s_at) { add(stream.p + s_at, d_at, so - s_at); d_at += so - s_at; s_at = so; }
+        const size_t hn = marks[i + 1] - marks[i];
+        if (hn) { add(hb.p + marks[i], d_at, hn); d_at += hn; }
+    }
+    if (stream.size() > s_at) add(stream.p + s_at, d_at, stream.size() - s_at);
+    int T = n_threads < 1 ? 1 : n_threads;
+    if (total < (4u << 20)) T = 1;
+    std::vector<std::thread> th;
+    auto work = [&](int t) { for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)T) memcpy(out.p + pieces[i].dst, pieces[i].src, pieces[i].n); };
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
     for (auto &x : th) x.join();
 }
 

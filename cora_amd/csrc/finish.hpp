@@ -46,6 +46,13 @@ struct ExactDeviceResult {             // classes with >= 2 entries, sorted by r
     View<uint8_t> merge_prev;          // class continues the block of the previous class
 };
 
+// a list of <Inexact> that the host finishes (tied targets in its run, or more than 16 items)
+struct HostNode {
+    uint32_t node, count, tie, reserved;
+    uint64_t stream_off;               // where its bytes belong in the device-written stream
+    uint64_t item_off;                 // its items in the compacted host arrays
+};
+
 struct InexactDeviceResult {           // directed items sorted by (source, target)
     View<uint64_t> key;                // src<<32 | tgt
     View<uint32_t> meta;               // kernels.hpp bit layout
@@ -72,6 +79,9 @@ void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, ByteBuf &o
 // packed: the 2-bit genome (needed only when a list has tied targets); may be empty if none has.
 // n_threads host threads each serialise a contiguous range of source positions.
 void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
-                       ByteBuf &out, FinishStats &st, int n_threads);
+                       ByteBuf &out, FinishStats &st, int n_threads, std::vector<size_t> *marks = nullptr);
+// Splices the host-finished lists into the byte stream the device wrote (stages.hip, st_items_finish).
+void assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
+                      View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads);
 
 }  // namespace cora

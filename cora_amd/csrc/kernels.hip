@@ -837,8 +837,210 @@ __global__ __launch_bounds__(256) void k_chain(DevParams p, const u64 *__restric
     blen[i] = (int16_t)L;
 }
 
+
+// ------------------------------------------------------------------ <Inexact> bytes on the device
+// Lists (nodes) whose final order needs no library sort are written by the GPU: a list of at most 16 items
+// goes through libstdc++'s std::sort as a plain insertion sort, i.e. stably, so "by decreasing block length,
+// ties in target order" is the reference's order (HTS:1368).  Longer lists (introsort, unstable) and every
+// list of a run of consecutive positions that holds tied targets (the block lengths themselves then depend
+// on the reference's push order) are left to the host, which receives just those lists.
+
+// per list: does it hold a tied target; does it open a run of consecutive source positions (HTS:1212)
+__global__ __launch_bounds__(256) void k_node_class(DevParams p, const u64 *__restrict__ item_key, const u32 *__restrict__ node_start,
+                                                    u32 n_nodes, u32 *__restrict__ run_head, u32 *__restrict__ node_tie)
+{
+    const u32 nd = blockIdx.x * 256 + threadIdx.x;
+    if (nd >= n_nodes) return;
+    const u32 a = node_start[nd], b = node_start[nd + 1];
+    bool tie = false;
+    u64 prev = item_key[a];
+    for (u32 k = a + 1; k < b; k++) { const u64 x = item_key[k]; tie |= (x == prev); prev = x; }
+    const u64 src = item_key[a] >> 32;
+    bool head = true;
+    if (nd > 0 && src > 0 && (item_key[node_start[nd - 1]] >> 32) == src - 1 && same_window(p, src - 1, src)) head = false;
+    run_head[nd] = head ? 1u : 0u;
+    node_tie[nd] = tie ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_run_dirty(const u32 *__restrict__ node_tie, const u64 *__restrict__ run_excl,
+                                                   const u32 *__restrict__ run_head, u32 n_nodes, u32 *__restrict__ run_dirty)
+{
+    const u32 nd = blockIdx.x * 256 + threadIdx.x;
+    if (nd < n_nodes && node_tie[nd]) run_dirty[run_excl[nd] + run_head[nd] - 1] = 1u;
+}
+
+// bytes of every device-written list (0 for host lists and for lists whose items were all absorbed)
+__global__ __launch_bounds__(256) void k_node_size(DevParams p, int cw, const u32 *__restrict__ node_start, const int16_t *__restrict__ blen,
+                                                   const u64 *__restrict__ run_excl, const u32 *__restrict__ run_head,
+                                                   const u32 *__restrict__ run_dirty, u32 n_nodes, u32 *__restrict__ size,
+                                                   u32 *__restrict__ hflag, u32 *__restrict__ hcnt, DevCounters *ctr)
+{
+    __shared__ u32 s_emit[4];
+    const u32 nd = blockIdx.x * 256 + threadIdx.x;
+    bool emitted = false;
+    if (nd < n_nodes) {
+        const u32 a = node_start[nd], b = node_start[nd + 1], cnt = b - a;
+        const bool dirty = run_dirty[run_excl[nd] + run_head[nd] - 1] != 0;
+        const bool host = dirty || cnt > 16;
+        u32 sz = 0;
+        if (!host) {
+            u32 alive = 0;
+            for (u32 k = a; k < b; k++) alive += (blen[k] != -1) ? 1u : 0u;
+            if (alive) sz = (u32)(cw + 4) + alive * (u32)(1 + cw + 4 + p.d + 2) + 1u;
+            emitted = alive != 0;
+        }
+        size[nd] = sz;
+        hflag[nd] = host ? 1u : 0u;
+        hcnt[nd] = host ? cnt : 0u;
+    }
+    const u64 bal = __ballot(emitted);
+    if ((threadIdx.x & 63) == 0) s_emit[threadIdx.x >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 t = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3];
+        if (t) atomicAdd(&ctr->emitted_nodes, (unsigned long long)t);
+    }
+}
+
+__device__ __forceinline__ u8 *put_chr(u8 *w, int cw, u32 c) { *w++ = (u8)c; if (cw == 2) *w++ = (u8)(c >> 8); return w; }
+__device__ __forceinline__ u8 *put_u32(u8 *w, u32 x) { w[0] = (u8)x; w[1] = (u8)(x >> 8); w[2] = (u8)(x >> 16); w[3] = (u8)(x >> 24); return w + 4; }
+
+// F2 bytes of the device lists (HTS:1353-1432); host lists: descriptor + their items, compacted
+__global__ __launch_bounds__(256) void k_node_write(DevParams p, int cw, const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
+                                                    const int16_t *__restrict__ blen, const u32 *__restrict__ node_start, u32 n_nodes,
+                                                    const u32 *__restrict__ size, const u64 *__restrict__ off, const u32 *__restrict__ hflag,
+                                                    const u64 *__restrict__ hidx, const u64 *__restrict__ hoff, const u32 *__restrict__ node_tie,
+                                                    u8 *__restrict__ stream, HostNode *__restrict__ hnodes, u64 *__restrict__ h_key,
+                                                    u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen)
+{
+    const u32 nd = blockIdx.x * 256 + threadIdx.x;
+    if (nd >= n_nodes) return;
+    const u32 a = node_start[nd], b = node_start[nd + 1];
+    if (hflag[nd]) {
+        HostNode h;
+        h.node = nd; h.count = b - a; h.tie = node_tie[nd]; h.reserved = 0;
+        h.stream_off = off[nd]; h.item_off = hoff[nd];
+        hnodes[hidx[nd]] = h;
+        for (u32 k = a; k < b; k++) {
+            const u64 o = h.item_off + (k - a);
+            h_key[o] = item_key[k]; h_meta[o] = item_meta[k]; h_blen[o] = blen[k];
+        }
+        return;
+    }
+    if (!size[nd]) return;
+    u8 *w = stream + off[nd];
+    const u64 src = item_key[a] >> 32;
+    const u32 sc = find_contig(p, src);
+    w = put_chr(w, cw, sc + 1);
+    w = put_u32(w, (u32)(src - p.ctg_gstart[sc]) + 1);
+    // by decreasing block length, ties in list (= target) order: pick the successor of the last one written
+    int last_len = 32767 + 1;
+    u32 last_k = 0;
+    for (;;) {
+        int best_len = -2;
+        u32 best_k = 0;
+        for (u32 k = a; k < b; k++) {
+            const int L = blen[k];
+            if (L == -1) continue;
+            const bool after = (L < last_len) || (L == last_len && k > last_k);
+            if (after && L > best_len) { best_len = L; best_k = k; }      // first k wins among equal lengths
+        }
+        if (best_len == -2) break;
+        const u32 m = item_meta[best_k];
+        const u64 tgt = item_key[best_k] & 0xFFFFFFFFull;
+        const u32 tc = find_contig(p, tgt);
+        *w++ = (u8)(m & 1u);
+        w = put_chr(w, cw, tc + 1);
+        w = put_u32(w, (u32)(tgt - p.ctg_gstart[tc]) + 1);
+        *w++ = (u8)meta_o1(m);
+        if (p.d > 1) *w++ = (u8)meta_o2(m);
+        if (p.d > 2) *w++ = (u8)meta_o3(m);
+        *w++ = (u8)best_len; *w++ = (u8)((u32)best_len >> 8);
+        last_len = best_len; last_k = best_k;
+    }
+    *w++ = 0xFF;
+}
+
+
+// ------------------------------------------------------------------ <Exact> bytes on the device
+// F1 (HTS:572-635): per block of merged classes, the first class only:  chr pos { dir chr pos }*  0xFF  blockSize(u32)
+__global__ __launch_bounds__(256) void k_exact_size(int cw, const u32 *__restrict__ cls_entries, const u8 *__restrict__ merge_prev, u32 n_cls,
+                                                    u32 *__restrict__ size, DevCounters *ctr)
+{
+    __shared__ u32 s_emit[4];
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    bool head = false;
+    if (c < n_cls) {
+        head = !merge_prev[c];
+        const u32 ne = cls_entries[c];
+        size[c] = head ? ne * (u32)(cw + 4) + (ne - 1) + 5u : 0u;
+    }
+    const u64 bal = __ballot(head);
+    if ((threadIdx.x & 63) == 0) s_emit[threadIdx.x >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 t = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3];
+        if (t) atomicAdd(&ctr->emitted_exact, (unsigned long long)t);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_exact_write(DevParams p, int cw, const u32 *__restrict__ cls_entries, const u64 *__restrict__ ent_off,
+                                                     const u32 *__restrict__ ent, const u8 *__restrict__ ent_dir,
+                                                     const u8 *__restrict__ merge_prev, u32 n_cls, const u32 *__restrict__ size,
+                                                     const u64 *__restrict__ off, u8 *__restrict__ stream)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cls || !size[c]) return;
+    u8 *w = stream + off[c];
+    const u64 o = ent_off[c];
+    const u32 ne = cls_entries[c];
+    for (u32 k = 0; k < ne; k++) {
+        const u64 gp = ent[o + k];
+        const u32 ci = find_contig(p, gp);
+        if (k) *w++ = ent_dir[o + k];
+        w = put_chr(w, cw, ci + 1);
+        w = put_u32(w, (u32)(gp - p.ctg_gstart[ci]) + 1);
+    }
+    *w++ = 0xFF;
+    u32 e = c + 1;
+    while (e < n_cls && merge_prev[e]) e++;
+    w = put_u32(w, e - c);
+}
+
 // ------------------------------------------------------------------ launch wrappers
 static inline dim3 grid_for(u64 n) { return dim3((unsigned)((n + 255) / 256)); }
+
+void launch_exact_size(hipStream_t s, int cw, const u32 *cls_entries, const u8 *merge_prev, u32 n_cls, u32 *size, DevCounters *ctr)
+{
+    if (n_cls) hipLaunchKernelGGL(k_exact_size, grid_for(n_cls), dim3(256), 0, s, cw, cls_entries, merge_prev, n_cls, size, ctr);
+}
+void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cls_entries, const u64 *ent_off, const u32 *ent, const u8 *ent_dir,
+                        const u8 *merge_prev, u32 n_cls, const u32 *size, const u64 *off, u8 *stream)
+{
+    if (n_cls) hipLaunchKernelGGL(k_exact_write, grid_for(n_cls), dim3(256), 0, s, p, cw, cls_entries, ent_off, ent, ent_dir, merge_prev, n_cls,
+                                  size, off, stream);
+}
+void launch_node_class(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *node_start, u32 n_nodes, u32 *run_head, u32 *node_tie)
+{
+    if (n_nodes) hipLaunchKernelGGL(k_node_class, grid_for(n_nodes), dim3(256), 0, s, p, item_key, node_start, n_nodes, run_head, node_tie);
+}
+void launch_run_dirty(hipStream_t s, const u32 *node_tie, const u64 *run_excl, const u32 *run_head, u32 n_nodes, u32 *run_dirty)
+{
+    if (n_nodes) hipLaunchKernelGGL(k_run_dirty, grid_for(n_nodes), dim3(256), 0, s, node_tie, run_excl, run_head, n_nodes, run_dirty);
+}
+void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node_start, const int16_t *blen, const u64 *run_excl,
+                      const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, DevCounters *ctr)
+{
+    if (n_nodes) hipLaunchKernelGGL(k_node_size, grid_for(n_nodes), dim3(256), 0, s, p, cw, node_start, blen, run_excl, run_head, run_dirty,
+                                    n_nodes, size, hflag, hcnt, ctr);
+}
+void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
+                       const u32 *node_start, u32 n_nodes, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
+                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen)
+{
+    if (n_nodes) hipLaunchKernelGGL(k_node_write, grid_for(n_nodes), dim3(256), 0, s, p, cw, item_key, item_meta, blen, node_start, n_nodes,
+                                    size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen);
+}
 
 void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr)
 {

@@ -151,7 +151,6 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
 {
     hipStream_t s = job->stream;
     const DevParams &dp = job->dp;
-    ExactDeviceResult er;
     const u64 n = p.NNS;
     if (n >= (1ull << 32)) return fail(19, "too many classes");
     if (n) {
@@ -167,18 +166,38 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
         if (radix_sort(s, ck, ct, n, 32, 32 + bits_for(dp.G), job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
         launch_gather_parts(s, ck.a, (u32)n, p.ce.p, eoff.p, ce_s.p, eoff_s.p);
         launch_class_merge(s, ck.a, (u32)n, ce_s.p, eoff_s.p, p.ent.p, p.edir.p, mp.p);
-        RCQ(d2h(job, job->h_cls, er.cls, (const u64 *)ck.a, n));
-        RCQ(d2h(job, job->h_cls_entries, er.cls_entries, (const u32 *)ce_s.p, n));
-        RCQ(d2h(job, job->h_ent_off, er.ent_off, (const u64 *)eoff_s.p, n));
-        RCQ(d2h(job, job->h_ent, er.ent, (const u32 *)p.ent.p, p.NE));
-        RCQ(d2h(job, job->h_ent_dir, er.ent_dir, (const u8 *)p.edir.p, p.NE));
-        RCQ(d2h(job, job->h_merge_prev, er.merge_prev, (const u8 *)mp.p, n));
+        // F1 bytes on the device: sizes, offsets, bytes; only the bytes cross to the host
+        const int cw = job->prm.chr_short ? 2 : 1;
+        DBuf<u32> csize;
+        DBuf<u64> coff, tot;
+        RCQ(csize.alloc(n)); RCQ(coff.alloc(n)); RCQ(tot.alloc(1));
+        DevCounters h;
+        RCQ(read_counters(job, h));
+        h.emitted_exact = 0;
+        RCQ(write_counters(job, h));
+        launch_exact_size(s, cw, ce_s.p, mp.p, (u32)n, csize.p, job->ctr.p);
+        if (exclusive_scan_u32_to_u64(s, csize.p, coff.p, n, scr.p, tot.p)) return fail(100, "scan launch failed");
+        u64 total = 0;
+        HIPQ(hipMemcpyAsync(&total, tot.p, sizeof total, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
+        DBuf<u8> stream;
+        RCQ(stream.alloc(total));
+        launch_exact_write(s, dp, cw, ce_s.p, eoff_s.p, p.ent.p, p.edir.p, mp.p, (u32)n, csize.p, coff.p, stream.p);
+        View<u8> bytes;
+        RCQ(d2h(job, job->h_stream, bytes, (const u8 *)stream.p, total));
+        RCQ(read_counters(job, h));
         HIPQ(hipGetLastError());
+        const auto h0 = std::chrono::steady_clock::now();
+        job->exact_bytes.reserve_uninit(total + 16);
+        if (total) memcpy(job->exact_bytes.p, bytes.p, total);
+        job->exact_bytes.n = total;
+        fst.exact_nodes = h.emitted_exact;
+        host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+    } else {
+        job->exact_bytes.reserve_uninit(16);
+        job->exact_bytes.n = 0;
+        fst.exact_nodes = 0;
     }
-    const auto h0 = std::chrono::steady_clock::now();
-    serialize_exact(job->hg, er, job->exact_bytes, fst);
-    host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     return 0;
 }
 
@@ -258,8 +277,11 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
-    InexactDeviceResult ir;
+    InexactDeviceResult ir;                 // the items of the lists the host finishes
     View<u64> packed_host;
+    View<u8> stream_host;
+    View<HostNode> hnodes_host;
+    u64 device_nodes = 0;
     static const u32 zero_node = 0;
     if (M >= (1ull << 32)) return fail(19, "too many directed items (%llu)", (unsigned long long)M);
     job->stats.inexact_items = M;
@@ -289,20 +311,60 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         HIPQ(hipMemcpyAsync(nstart.p + n_nodes, &m32, sizeof(u32), hipMemcpyHostToDevice, s));
         launch_chain(s, dp, kk.a, kk.c, hf.p, nexcl.p, nstart.p, (u32)n_nodes, M, blen.p);
         HIPQ(hipGetLastError());
-        RCQ(d2h(job, job->h_key, ir.key, (const u64 *)kk.a, M));
-        RCQ(d2h(job, job->h_meta, ir.meta, (const u32 *)kk.c, M));
-        RCQ(d2h(job, job->h_blen, ir.blen, (const int16_t *)blen.p, M));
-        RCQ(d2h(job, job->h_node_start, ir.node_start, (const u32 *)nstart.p, n_nodes + 1));
+        // ---- bytes: lists the device can order itself are written here; the others go to the host (kernels.hip) ----
+        const int cw = job->prm.chr_short ? 2 : 1;
+        const u32 nn = (u32)n_nodes;
+        DBuf<u32> run_head, node_tie, run_dirty, nsize, hflag, hcnt;
+        DBuf<u64> run_excl, noff, hidx, hoff, tots;
+        RCQ(run_head.alloc(nn)); RCQ(node_tie.alloc(nn)); RCQ(run_dirty.alloc(nn)); RCQ(nsize.alloc(nn)); RCQ(hflag.alloc(nn)); RCQ(hcnt.alloc(nn));
+        RCQ(run_excl.alloc(nn)); RCQ(noff.alloc(nn)); RCQ(hidx.alloc(nn)); RCQ(hoff.alloc(nn)); RCQ(tots.alloc(4));
         RCQ(read_counters(job, h));
+        h.emitted_nodes = 0;
+        RCQ(write_counters(job, h));
+        launch_node_class(s, dp, kk.a, nstart.p, nn, run_head.p, node_tie.p);
+        if (exclusive_scan_u32_to_u64(s, run_head.p, run_excl.p, nn, scr.p, nullptr)) return fail(100, "scan launch failed");
+        HIPQ(hipMemsetAsync(run_dirty.p, 0, (size_t)nn * sizeof(u32), s));
+        launch_run_dirty(s, node_tie.p, run_excl.p, run_head.p, nn, run_dirty.p);
+        launch_node_size(s, dp, cw, nstart.p, blen.p, run_excl.p, run_head.p, run_dirty.p, nn, nsize.p, hflag.p, hcnt.p, job->ctr.p);
+        if (exclusive_scan_u32_to_u64(s, nsize.p, noff.p, nn, scr.p, tots.p)) return fail(100, "scan launch failed");
+        if (exclusive_scan_u32_to_u64(s, hflag.p, hidx.p, nn, scr.p, tots.p + 1)) return fail(100, "scan launch failed");
+        if (exclusive_scan_u32_to_u64(s, hcnt.p, hoff.p, nn, scr.p, tots.p + 2)) return fail(100, "scan launch failed");
+        u64 totals[3] = {0, 0, 0};                          // stream bytes, host lists, their items
+        HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        DBuf<u8> stream;
+        DBuf<HostNode> hnodes;
+        DBuf<u64> hk;
+        DBuf<u32> hm;
+        DBuf<int16_t> hbl;
+        RCQ(stream.alloc(totals[0])); RCQ(hnodes.alloc(totals[1])); RCQ(hk.alloc(totals[2])); RCQ(hm.alloc(totals[2])); RCQ(hbl.alloc(totals[2]));
+        launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, nn, nsize.p, noff.p, hflag.p, hidx.p, hoff.p, node_tie.p, stream.p,
+                          hnodes.p, hk.p, hm.p, hbl.p);
+        HIPQ(hipGetLastError());
+        RCQ(d2h(job, job->h_stream, stream_host, (const u8 *)stream.p, totals[0]));
+        RCQ(d2h(job, job->h_hnodes, hnodes_host, (const HostNode *)hnodes.p, totals[1]));
+        RCQ(d2h(job, job->h_key, ir.key, (const u64 *)hk.p, totals[2]));
+        RCQ(d2h(job, job->h_meta, ir.meta, (const u32 *)hm.p, totals[2]));
+        RCQ(d2h(job, job->h_blen, ir.blen, (const int16_t *)hbl.p, totals[2]));
+        RCQ(read_counters(job, h));
+        device_nodes = h.emitted_nodes;
         if (h.n_dirty) RCQ(d2h(job, job->h_packed, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
         HIPQ(hipStreamSynchronize(s));
+        // list starts of the compacted host items
+        RCQ(job->h_node_start.reserve(totals[1] + 1));
+        for (u64 i = 0; i < totals[1]; i++) job->h_node_start.p[i] = (u32)hnodes_host[i].item_off;
+        job->h_node_start.p[totals[1]] = (u32)totals[2];
+        ir.node_start.p = job->h_node_start.p; ir.node_start.n = totals[1] + 1;
     } else {
         ir.node_start.p = &zero_node; ir.node_start.n = 1;
     }
     HIPQ(hipEventRecord(job->ev[4], s));
     HIPQ(hipStreamSynchronize(s));
     const auto h0 = std::chrono::steady_clock::now();
-    serialize_inexact(job->hg, ir, packed_host, job->inexact_bytes, fst, job->host_threads);
-    host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+    assemble_inexact(job->hg, stream_host, hnodes_host, ir, packed_host, device_nodes, job->inexact_bytes, fst, job->host_threads);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+    host_ms += ms;
+    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] inexact host finish %.3f ms (%zu stream bytes, %zu host lists, %zu host items)\n", ms,
+                                      stream_host.size(), hnodes_host.size(), ir.key.size());
     return 0;
 }
