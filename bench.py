@@ -58,6 +58,21 @@ def cpu_baseline(K, d, sample_bases, tmp):
             "sample": "chr20_like generator at %d bp (K=%d d=%d, -p 1 -t %d), %.1f s wall" % (sample_bases, K, d, threads, dt)}
 
 
+def pmc_traffic(bases, K, d):
+    """HBM bytes per rs_scatter launch from the newest committed PMC summary of this very workload
+    (profiles/collect.sh + summarize.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for gfx950)."""
+    import glob
+    want = "chr20_like %d bp K=%d d=%d" % (bases, K, d)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if t.get("workload") == want:
+            return t["bytes_per_launch"], t.get("source")
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +148,7 @@ def main():
 
     if rank == 0:
         achieved = (sc_bytes / 1e9) / (sc_ms / 1e3) if sc_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(a.bases, K, d) if world == 1 else (None, None)
         out = {
             "metric": "ref k-mers/sec into homology table (d=2)", "value": kmers_all * a.steps / dt, "unit": "k-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -149,7 +165,8 @@ def main():
             "stage_ms": {k: round(st[k], 3) for k in ("ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total")},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter (LSD radix scatter, all sorts of the path)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "launches_per_step": sc_n // max(1, a.steps), "avg_launch_ms": sc_ms / max(1, sc_n), "traffic": None},
+                         "launches_per_step": sc_n // max(1, a.steps), "avg_launch_ms": sc_ms / max(1, sc_n),
+                         "algorithmic_bytes_per_launch": sc_bytes / max(1, sc_n), "traffic": traffic, "traffic_source": traffic_src},
         }
         cb = cpu_baseline(K, d, a.cpu_sample, tmp) if (a.cpu_sample > 0 and world == 1) else None
         out["cpu_baseline"] = cb

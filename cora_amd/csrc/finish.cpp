@@ -91,34 +91,6 @@ struct Writer {                                           // raw cursor into a b
 
 }  // namespace
 
-// F1 (HTS:572-635): rep chr,pos  { dir chr pos }*  0xFF  blockSize; only a block's first class is written.
-void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, ByteBuf &out, FinishStats &st)
-{
-    const size_t n = r.cls.size();
-    const int cw = g.chr_short ? 2 : 1;
-    out.reserve_uninit(r.ent.size() * (size_t)(1 + cw + 4) + n * 5 + 16);
-    Writer w{out.p, cw};
-    st.exact_nodes = 0;
-    for (size_t c = 0; c < n;) {
-        size_t e = c + 1;
-        while (e < n && r.merge_prev[e]) e++;
-        const uint64_t o = r.ent_off[c];
-        const uint32_t ne = r.cls_entries[c];
-        for (uint32_t k = 0; k < ne; k++) {
-            const uint32_t gp = r.ent[o + k];
-            const uint32_t ci = g.contig_of(gp);
-            if (k) w.u8(r.ent_dir[o + k]);
-            w.chr(ci + 1);
-            w.u32((uint32_t)(gp - g.gstart[ci]) + 1);
-        }
-        w.u8(0xFF);
-        w.u32((uint32_t)(e - c));
-        st.exact_nodes++;
-        c = e;
-    }
-    out.n = (size_t)(w.at - out.p);
-}
-
 namespace {
 
 struct DItem {                                            // one directed item in a list that needs the exact order

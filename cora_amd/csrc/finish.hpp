@@ -37,14 +37,6 @@ struct View {                          // borrowed array (pinned host memory own
     bool empty() const { return n == 0; }
 };
 
-struct ExactDeviceResult {             // classes with >= 2 entries, sorted by representative
-    View<uint64_t> cls;                // rep<<32 | start (start unused on the host)
-    View<uint32_t> cls_entries;        // entries per class (representative included)
-    View<uint64_t> ent_off;            // first entry of each class
-    View<uint32_t> ent;                // entry positions (global coordinate)
-    View<uint8_t> ent_dir;             // entry directions
-    View<uint8_t> merge_prev;          // class continues the block of the previous class
-};
 
 // a list of <Inexact> that the host finishes (tied targets in its run, or more than 16 items)
 struct HostNode {
@@ -75,7 +67,6 @@ struct ByteBuf {
 
 struct FinishStats { uint64_t exact_nodes = 0, inexact_nodes = 0, dirty_nodes = 0, big_nodes = 0; };
 
-void serialize_exact(const HostGenome &g, const ExactDeviceResult &r, ByteBuf &out, FinishStats &st);
 // packed: the 2-bit genome (needed only when a list has tied targets); may be empty if none has.
 // n_threads host threads each serialise a contiguous range of source positions.
 void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,

@@ -141,9 +141,9 @@ struct cora_hip_job {
     SortScratch sort_scratch;
     SortTiming sort_timing;
     DevPool pool;
-    HBuf<u64> h_cls, h_ent_off, h_key, h_packed;
-    HBuf<u32> h_cls_entries, h_ent, h_meta, h_node_start;
-    HBuf<u8> h_ent_dir, h_merge_prev, h_stream;
+    HBuf<u64> h_key, h_packed;
+    HBuf<u32> h_meta, h_node_start;
+    HBuf<u8> h_stream;
     HBuf<HostNode> h_hnodes;
     HBuf<int16_t> h_blen;
     int host_threads = 8;
