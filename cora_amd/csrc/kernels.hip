@@ -1222,6 +1222,41 @@ __global__ __launch_bounds__(256) void k_count_dest(const u64 *__restrict__ dest
     if (threadIdx.x < world && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+// Multi-GPU item routing.  Lists are finished by the rank that owns their source position; the owner intervals are
+// cut where a position holds no list, so that no run of consecutive positions (the unit of block merging) is split.
+// wc[b * win + j] = number of items whose source is position bnd[b] - 1 + j   (bnd[b] = nominal start of rank b + 1)
+__global__ __launch_bounds__(256) void k_window_counts(const u64 *__restrict__ item_key, u64 m, const u32 *__restrict__ bnd, u32 n_bnd,
+                                                       u32 win, u32 *__restrict__ wc)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const u64 src = item_key[i] >> 32;
+    for (u32 b = 0; b < n_bnd; b++) {
+        const u64 lo = (u64)bnd[b] - 1;                                   // bnd[b] >= 1 (checked by the host)
+        if (src >= lo && src < lo + win) atomicAdd(&wc[(u64)b * win + (src - lo)], 1u);
+    }
+}
+
+// dest = number of cuts <= source position (cuts ascending)
+__global__ __launch_bounds__(256) void k_dest_by_cuts(const u64 *__restrict__ item_key, u64 m, const u32 *__restrict__ cuts, u32 n_cuts,
+                                                      u64 *__restrict__ dest)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const u32 src = (u32)(item_key[i] >> 32);
+    u32 lo = 0, hi = n_cuts;                                              // first cut > src
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (cuts[mid] <= src) lo = mid + 1; else hi = mid; }
+    dest[i] = lo;
+}
+
+void launch_window_counts(hipStream_t s, const u64 *item_key, u64 m, const u32 *bnd, u32 n_bnd, u32 win, u32 *wc)
+{
+    if (m && n_bnd) hipLaunchKernelGGL(k_window_counts, grid_for(m), dim3(256), 0, s, item_key, m, bnd, n_bnd, win, wc);
+}
+void launch_dest_by_cuts(hipStream_t s, const u64 *item_key, u64 m, const u32 *cuts, u32 n_cuts, u64 *dest)
+{
+    if (m) hipLaunchKernelGGL(k_dest_by_cuts, grid_for(m), dim3(256), 0, s, item_key, m, cuts, n_cuts, dest);
+}
 void launch_keys_from_gpos(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, u64 n, u64 *hi, u64 *lo)
 {
     if (n) hipLaunchKernelGGL(k_keys_from_gpos, grid_for(n), dim3(256), 0, s, p, pk, gpos, n, hi, lo);

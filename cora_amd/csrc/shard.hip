@@ -10,8 +10,11 @@
 //   REPS       representatives inside the own position slice
 //   SEED s     their seed-s codes, partitioned by code hash                                  [all-to-all]
 //   VERIFY s   received codes -> sort, equal runs, verification against the local replica
-//   ITEMS      pair records -> directed items                                                [gather to rank 0]
-//   FINISH     rank 0: item sort, lists, block merge, final order, <Inexact> bytes
+//   ITEMS      pair records -> directed items; items per source position near the slice starts [all-reduce]
+//   ITEM_CUT   owner intervals cut where a position holds no list; items partitioned by owner  [all-to-all]
+//   FINISH     every rank: item sort, lists, block merge, final order, <Inexact> bytes of its interval
+//                                                                                  [gather of the bytes to rank 0, sum of the counts]
+//   COLLECT    rank 0: the ranks' byte ranges, in rank = position order, are the table
 //
 // Equal keys (codes) meet on one rank; inside each received chunk they are in increasing position and chunks
 // arrive in rank = position order, so the stable sorts see them exactly as the single-GPU run does.
@@ -32,6 +35,12 @@ struct ShardState {
     DBuf<u32> reps;
     u64 n_reps = 0;
     PairStore ps;
+    DBuf<u32> wcount, bnd_dev;          // items per source position in a window behind every nominal slice start
+    std::vector<u32> bnd;               // nominal slice starts of ranks 1..world-1 (positions)
+    u32 win = 0;
+    DBuf<u8> f2_dev, f2_all;            // this rank's <Inexact> bytes / all ranks' bytes (rank 0)
+    u64 n_f2 = 0, n_f2_all = 0;
+    DBuf<u64> stat_dev;                 // counts summed over ranks
     FinishStats fst;
     double host_ms = 0;
     std::chrono::steady_clock::time_point t_begin;
@@ -46,8 +55,9 @@ void shard_state_free(cora_hip_job *job)
 }
 
 enum { SLOT_SEND_A = 0, SLOT_SEND_C, SLOT_RECV_A, SLOT_RECV_C, SLOT_REPMASK, SLOT_X_CLS, SLOT_X_CNT, SLOT_X_ENT, SLOT_X_DIR,
-       SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_COUNT };
-enum { ST_KMERS = 1, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH };
+       SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_WCOUNT, SLOT_F2, SLOT_RX_F2, SLOT_STATS, SLOT_COUNT };
+enum { ST_KMERS = 1, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH, ST_ITEM_CUT, ST_COLLECT };
+constexpr u32 N_STATS = 8;              // inexact_nodes, dirty, big, inexact_items, hom_pairs, candidate_pairs, 2 spare
 
 // stable partition of (a[, c]) by destination rank; counts[r] = records for rank r
 static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts)
@@ -170,8 +180,64 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         sh.ps.pairs.release(); sh.ps.n = sh.ps.cap = 0;
         sh.reps.release(); sh.repmask_g.release();
         sh.n_send = M;
+        // items per source position in a window behind each nominal slice start (summed over ranks by the caller)
+        sh.bnd.clear();
+        const u64 n_blocks = (dp.G + 255) / 256;
+        for (int r = 1; r < sh.world; r++) sh.bnd.push_back((u32)(n_blocks * r / sh.world * 256));
+        sh.win = 1u << 16;
+        const u64 nb = sh.bnd.size();
+        RCQ(sh.wcount.alloc(nb * sh.win)); RCQ(sh.bnd_dev.alloc(nb));
+        if (nb) {
+            HIPQ(hipMemsetAsync(sh.wcount.p, 0, nb * sh.win * sizeof(u32), s));
+            std::vector<u32> starts(sh.bnd);
+            for (u32 &b : starts) if (b == 0) b = 1;          // fewer blocks than ranks: the kernel needs a start >= 1; the cut is 0 anyway
+            HIPQ(hipMemcpyAsync(sh.bnd_dev.p, starts.data(), nb * sizeof(u32), hipMemcpyHostToDevice, s));
+            launch_window_counts(s, sh.send_a.p, M, sh.bnd_dev.p, (u32)nb, sh.win, sh.wcount.p);
+            HIPQ(hipStreamSynchronize(s));
+            HIPQ(hipGetLastError());
+        }
+        return 0;
+    }
+    case ST_ITEM_CUT: {
+        // cut r = first position >= the nominal start of rank r whose predecessor holds no list; every rank computes the
+        // same cuts from the same summed counts.  No such position inside a window: rank 0 takes every item.
+        const u64 nb = sh.bnd.size();
+        std::vector<u32> wc(nb * sh.win), cuts(nb, 0xFFFFFFFFu);
+        if (nb) {
+            HIPQ(hipMemcpyAsync(wc.data(), sh.wcount.p, nb * sh.win * sizeof(u32), hipMemcpyDeviceToHost, s));
+            HIPQ(hipStreamSynchronize(s));
+            bool all = true;
+            for (u64 b = 0; b < nb; b++) {
+                if (sh.bnd[b] == 0) { cuts[b] = 0; continue; }
+                u32 j = 0;
+                while (j < sh.win && wc[b * sh.win + j]) j++;
+                if (j == sh.win) { all = false; break; }
+                cuts[b] = sh.bnd[b] + j;
+            }
+            if (!all) std::fill(cuts.begin(), cuts.end(), 0xFFFFFFFFu);
+        }
         for (int r = 0; r < sh.world; r++) counts[r] = 0;
-        counts[0] = M;                                       // every item goes to rank 0
+        if (sh.world == 1 || sh.n_send == 0) { counts[0] = sh.world == 1 ? sh.n_send : 0; return 0; }
+        DBuf<u64> dest, tdest, ta;
+        DBuf<u32> tc, cuts_dev;
+        DBuf<unsigned long long> dcnt;
+        const u64 n = sh.n_send;
+        RCQ(dest.alloc(n)); RCQ(tdest.alloc(n)); RCQ(ta.alloc(n)); RCQ(tc.alloc(n)); RCQ(dcnt.alloc(256)); RCQ(cuts_dev.alloc(nb));
+        HIPQ(hipMemcpyAsync(cuts_dev.p, cuts.data(), nb * sizeof(u32), hipMemcpyHostToDevice, s));
+        HIPQ(hipMemsetAsync(dcnt.p, 0, 256 * sizeof(unsigned long long), s));
+        launch_dest_by_cuts(s, sh.send_a.p, n, cuts_dev.p, (u32)nb, dest.p);
+        launch_count_dest(s, dest.p, n, (u32)sh.world, dcnt.p);
+        SortArrays keys, tmp;
+        keys.a = dest.p; keys.b = sh.send_a.p; keys.c = sh.send_c.p;
+        tmp.a = tdest.p; tmp.b = ta.p; tmp.c = tc.p;
+        if (radix_sort(s, keys, tmp, n, 64, 72, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+        unsigned long long h[256];
+        HIPQ(hipMemcpyAsync(h, dcnt.p, sizeof h, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        HIPQ(hipGetLastError());
+        if (keys.b != sh.send_a.p) { std::swap(sh.send_a.p, ta.p); std::swap(sh.send_c.p, tc.p); }
+        for (int r = 0; r < sh.world; r++) counts[r] = h[r];
+        sh.wcount.release(); sh.bnd_dev.release();
         return 0;
     }
     case ST_FINISH: {
@@ -181,11 +247,32 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         cora_hip_stats &st = job->stats;
         st.exact_nodes = sh.fst.exact_nodes; st.inexact_nodes = sh.fst.inexact_nodes;
         st.dirty_nodes = sh.fst.dirty_nodes; st.big_nodes = sh.fst.big_nodes;
+        // this rank's bytes and counts, for the gather / the sum
+        sh.n_f2 = job->inexact_bytes.size();
+        RCQ(sh.f2_dev.alloc(sh.n_f2)); RCQ(sh.stat_dev.alloc(N_STATS));
+        if (sh.n_f2) HIPQ(hipMemcpyAsync(sh.f2_dev.p, job->inexact_bytes.data(), sh.n_f2, hipMemcpyHostToDevice, s));
+        const u64 hs[N_STATS] = {st.inexact_nodes, st.dirty_nodes, st.big_nodes, st.inexact_items, st.hom_pairs, st.candidate_pairs, 0, 0};
+        HIPQ(hipMemcpyAsync(sh.stat_dev.p, hs, sizeof hs, hipMemcpyHostToDevice, s));
+        HIPQ(hipStreamSynchronize(s));
         st.ms_host_finish = (float)sh.host_ms;
         st.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t_begin).count();
         st.ms_sort_scatter = job->sort_timing.scatter_ms;
         st.n_sort_scatter = job->sort_timing.scatter_launches;
         st.sort_scatter_bytes = job->sort_timing.scatter_bytes;
+        return 0;
+    }
+    case ST_COLLECT: {                  // rank 0: the table is the ranks' byte ranges in rank order; counts are the sums
+        cora_hip_stats &st = job->stats;
+        job->inexact_bytes.reserve_uninit(sh.n_f2_all + 16);
+        if (sh.n_f2_all) HIPQ(hipMemcpyAsync(job->inexact_bytes.p, sh.f2_all.p, sh.n_f2_all, hipMemcpyDeviceToHost, s));
+        u64 hs[N_STATS] = {0};
+        if (sh.stat_dev.p) HIPQ(hipMemcpyAsync(hs, sh.stat_dev.p, sizeof hs, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        job->inexact_bytes.n = sh.n_f2_all;
+        st.inexact_nodes = hs[0]; st.dirty_nodes = hs[1]; st.big_nodes = hs[2]; st.inexact_items = hs[3]; st.hom_pairs = hs[4];
+        st.candidate_pairs = hs[5];
+        sh.f2_all.release(); sh.f2_dev.release();
+        st.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t_begin).count();
         return 0;
     }
     default:
@@ -205,6 +292,9 @@ static int slot_ref(ShardState &sh, const DevParams &dp, int slot, void **p, u64
     case SLOT_X_CNT: *p = sh.parts.ce.p; *n = sh.parts.NNS; *eb = 4; return 0;
     case SLOT_X_ENT: *p = sh.parts.ent.p; *n = sh.parts.NE; *eb = 4; return 0;
     case SLOT_X_DIR: *p = sh.parts.edir.p; *n = sh.parts.NE; *eb = 1; return 0;
+    case SLOT_WCOUNT: *p = sh.wcount.p; *n = (u64)sh.bnd.size() * sh.win; *eb = 4; return 0;
+    case SLOT_F2: *p = sh.f2_dev.p; *n = sh.n_f2; *eb = 1; return 0;
+    case SLOT_STATS: *p = sh.stat_dev.p; *n = sh.stat_dev.p ? N_STATS : 0; *eb = 8; return 0;
     default: return 1;
     }
 }
@@ -248,6 +338,13 @@ extern "C" int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const voi
     case SLOT_RX_CNT: RCQ(sh.rparts.ce.alloc(n)); if (n != sh.rparts.NNS) return fail(19, "RX_CNT must match RX_CLS"); dst = sh.rparts.ce.p; eb = 4; break;
     case SLOT_RX_ENT: RCQ(sh.rparts.ent.alloc(n)); sh.rparts.NE = n; dst = sh.rparts.ent.p; eb = 4; break;
     case SLOT_RX_DIR: RCQ(sh.rparts.edir.alloc(n)); if (n != sh.rparts.NE) return fail(19, "RX_DIR must match RX_ENT"); dst = sh.rparts.edir.p; eb = 1; break;
+    case SLOT_WCOUNT:
+        if (n != (u64)sh.bnd.size() * sh.win || !sh.wcount.p) return fail(19, "window count size mismatch");
+        dst = sh.wcount.p; eb = 4; break;
+    case SLOT_RX_F2: RCQ(sh.f2_all.alloc(n)); sh.n_f2_all = n; dst = sh.f2_all.p; eb = 1; break;
+    case SLOT_STATS:
+        if (n != N_STATS || !sh.stat_dev.p) return fail(19, "stats size mismatch");
+        dst = sh.stat_dev.p; eb = 8; break;
     default: return fail(19, "slot %d cannot be imported", slot);
     }
     if (n) {

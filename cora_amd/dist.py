@@ -2,7 +2,8 @@
 
 The per-rank compute is libcora_hip.so's sharded stages (cora_amd/csrc/shard.hip); this module is the
 exchange plumbing between them: ``all_to_all_single`` of K-mer records by key-hash range, of seed records
-by code hash, a sum ``all_reduce`` of the representative bitmap (bits are disjoint, so sum = or), a min
+by code hash, of directed items by source interval, a sum ``all_reduce`` of the position bitmap of later class
+members (bits are disjoint, so sum = or) and of per-position item counts near the interval starts, a min
 ``all_reduce`` of the first-singleton key, and gathers to rank 0 for the two final tables.  With the
 ``nccl`` backend (= RCCL over xGMI) tensors stay in HBM; with ``gloo`` (CPU rehearsal of the same code
 path, e.g. two ranks sharing one GPU) they are staged through host memory.
@@ -18,9 +19,9 @@ import torch.distributed as dist
 
 from . import hip
 
-ST_KMERS, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH = range(1, 10)
+ST_KMERS, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH, ST_ITEM_CUT, ST_COLLECT = range(1, 12)
 (SLOT_SEND_A, SLOT_SEND_C, SLOT_RECV_A, SLOT_RECV_C, SLOT_REPMASK, SLOT_X_CLS, SLOT_X_CNT, SLOT_X_ENT, SLOT_X_DIR,
- SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR) = range(13)
+ SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_WCOUNT, SLOT_F2, SLOT_RX_F2, SLOT_STATS) = range(17)
 
 _DTYPE = {8: torch.int64, 4: torch.int32, 1: torch.uint8}
 NO_SINGLETON = (1 << 62)        # exchanged instead of ~0 (int64 min-reduce)
@@ -57,7 +58,7 @@ class Comm:
         return recv.to(self.device) if self.staged else recv
 
     def all_reduce_sum(self, t):
-        if self.local:
+        if self.local or t.numel() == 0:
             return t
         w = self._w(t)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
@@ -138,7 +139,14 @@ class ShardedJob:
         for seed in range(1, self.job.d + 2):
             self._route([(SLOT_SEND_A, SLOT_RECV_A)], self._stage(ST_SEED, seed))
             self._stage(ST_VERIFY, seed)
-        self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], self._stage(ST_ITEMS))
+        # lists are finished by the owner of their source position; intervals are cut where a position holds no list
+        self._stage(ST_ITEMS)
+        if not c.local:
+            self._import(SLOT_WCOUNT, c.all_reduce_sum(self._export(SLOT_WCOUNT)))
+        self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], self._stage(ST_ITEM_CUT))
+        self._stage(ST_FINISH)
+        self._gather_to_root([(SLOT_F2, SLOT_RX_F2)])
+        self._import(SLOT_STATS, c.all_reduce_sum(self._export(SLOT_STATS)))
         if c.rank == 0:
-            self._stage(ST_FINISH)
+            self._stage(ST_COLLECT)
         torch.cuda.synchronize()

@@ -111,10 +111,11 @@ int cora_hip_job_stats(const cora_hip_job *job, cora_hip_stats *out);
  * slot_export / slot_import are DEVICE pointers.  Restates, sharded, the same reference phases as
  * cora_hip_job_run (HTS:2499-2800, 249-1638). */
 enum cora_hip_shard_stage_id { CORA_ST_KMERS = 1, CORA_ST_EXACT, CORA_ST_PARTS, CORA_ST_MERGE, CORA_ST_REPS,
-                               CORA_ST_SEED, CORA_ST_VERIFY, CORA_ST_ITEMS, CORA_ST_FINISH };
+                               CORA_ST_SEED, CORA_ST_VERIFY, CORA_ST_ITEMS, CORA_ST_FINISH, CORA_ST_ITEM_CUT, CORA_ST_COLLECT };
 enum cora_hip_shard_slot_id { CORA_SLOT_SEND_A = 0, CORA_SLOT_SEND_C, CORA_SLOT_RECV_A, CORA_SLOT_RECV_C, CORA_SLOT_REPMASK,
                               CORA_SLOT_X_CLS, CORA_SLOT_X_CNT, CORA_SLOT_X_ENT, CORA_SLOT_X_DIR,
-                              CORA_SLOT_RX_CLS, CORA_SLOT_RX_CNT, CORA_SLOT_RX_ENT, CORA_SLOT_RX_DIR };
+                              CORA_SLOT_RX_CLS, CORA_SLOT_RX_CNT, CORA_SLOT_RX_ENT, CORA_SLOT_RX_DIR,
+                              CORA_SLOT_WCOUNT, CORA_SLOT_F2, CORA_SLOT_RX_F2, CORA_SLOT_STATS };
 int cora_hip_shard_begin(cora_hip_job *job, int rank, int world);
 /* Runs one stage; counts[world] (may be NULL) receives how many records of the SEND slots go to each rank. */
 int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint64_t *counts);

@@ -23,6 +23,8 @@ for name in os.environ["CORA_TEST_CASES"].split(","):
     job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
     job.set_reference_file(helpers.input_path(c["input"]))
     cdist.ShardedJob(job, comm).run()
+    if rank > 0:                                   # a later rank keeps the bytes of its own source interval
+        open(os.path.join(os.environ["CORA_TEST_OUT"], "%s.rank%d.bytes" % (name, rank)), "w").write(str(len(job.tables()[2])))
     if rank == 0:
         e, en, i, inn = job.tables()
         out = os.environ["CORA_TEST_OUT"]
