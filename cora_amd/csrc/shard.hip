@@ -309,6 +309,18 @@ extern "C" int cora_hip_shard_slot_info(cora_hip_job *job, int slot, uint64_t *n
     return 0;
 }
 
+// Device address of a slot's data (valid until the job's next stage / import call): lets the caller hand the
+// records to its collective library without a copy.
+extern "C" int cora_hip_shard_slot_ptr(cora_hip_job *job, int slot, void **ptr)
+{
+    if (!job || !job->shard || !ptr) return fail(19, "cora_hip_shard_begin has not run");
+    void *p; u64 n; u32 eb;
+    if (slot_ref(*job->shard, job->dp, slot, &p, &n, &eb)) return fail(19, "slot %d cannot be exported", slot);
+    HIPQ(hipStreamSynchronize(job->stream));
+    *ptr = n ? p : nullptr;
+    return 0;
+}
+
 extern "C" int cora_hip_shard_slot_export(cora_hip_job *job, int slot, void *dst_device)
 {
     if (!job || !job->shard) return fail(19, "cora_hip_shard_begin has not run");

@@ -24,6 +24,14 @@ ST_KMERS, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, S
  SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_WCOUNT, SLOT_F2, SLOT_RX_F2, SLOT_STATS) = range(17)
 
 _DTYPE = {8: torch.int64, 4: torch.int32, 1: torch.uint8}
+_TYPESTR = {8: "<i8", 4: "<i4", 1: "|u1"}
+
+
+class _DeviceArray:
+    """A slot of the library seen through ``__cuda_array_interface__``: torch wraps it without copying."""
+
+    def __init__(self, ptr, n, elem_bytes):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": _TYPESTR[elem_bytes], "data": (ptr, False), "version": 2}
 NO_SINGLETON = (1 << 62)        # exchanged instead of ~0 (int64 min-reduce)
 
 
@@ -85,6 +93,15 @@ class ShardedJob:
         self.h = job._h
 
     # ---- slots <-> torch tensors
+    def _view(self, slot):
+        """The slot's records as a tensor over the library's own memory (valid until the next stage / import)."""
+        n, eb, ptr = C.c_uint64(), C.c_uint32(), C.c_void_p()
+        hip._check(self.lib.cora_hip_shard_slot_info(self.h, slot, C.byref(n), C.byref(eb)))
+        hip._check(self.lib.cora_hip_shard_slot_ptr(self.h, slot, C.byref(ptr)))
+        if n.value == 0 or not ptr.value:
+            return torch.empty(0, dtype=_DTYPE[eb.value], device=self.comm.device)
+        return torch.as_tensor(_DeviceArray(ptr.value, n.value, eb.value), device=self.comm.device)
+
     def _export(self, slot):
         n, eb = C.c_uint64(), C.c_uint32()
         hip._check(self.lib.cora_hip_shard_slot_info(self.h, slot, C.byref(n), C.byref(eb)))
@@ -106,12 +123,12 @@ class ShardedJob:
         """pairs: [(send slot, recv slot)]; counts[r] records of each send slot go to rank r."""
         recv_counts = self.comm.exchange_counts(counts)
         for src, dst in pairs:
-            self._import(dst, self.comm.all_to_all(self._export(src), counts, recv_counts))
+            self._import(dst, self.comm.all_to_all(self._view(src), counts, recv_counts))
 
     def _gather_to_root(self, pairs):
         """Each (send slot, recv slot) may have its own length: everything goes to rank 0."""
         for src, dst in pairs:
-            t = self._export(src)
+            t = self._view(src)
             counts = [t.numel()] + [0] * (self.comm.world - 1)
             recv_counts = self.comm.exchange_counts(counts)
             self._import(dst, self.comm.all_to_all(t, counts, recv_counts))

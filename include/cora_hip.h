@@ -121,6 +121,8 @@ int cora_hip_shard_begin(cora_hip_job *job, int rank, int world);
 int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint64_t *counts);
 int cora_hip_shard_slot_info(cora_hip_job *job, int slot, uint64_t *n_elems, uint32_t *elem_bytes);
 int cora_hip_shard_slot_export(cora_hip_job *job, int slot, void *dst_device);
+/* Device address of a slot's data, valid until the job's next stage or import call (send without a copy). */
+int cora_hip_shard_slot_ptr(cora_hip_job *job, int slot, void **ptr);
 int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const void *src_device, uint64_t n_elems);
 int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
 int cora_hip_shard_set_first_singleton(cora_hip_job *job, uint64_t key);
