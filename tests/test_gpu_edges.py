@@ -1,0 +1,136 @@
+"""Edge inputs of the table build on the GPU: what the reference refuses or mis-handles must be refused here with the
+documented status; what it handles (many tiny contigs, no repeats at all, long low-complexity stretches, IUPAC letters)
+must match the oracle byte for byte, through the plain run and through the sharded stages."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from cora_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    hip.init(0)
+
+
+def _build(fa, K, d, p=1, t=1, L=False, sharded=False):
+    job = hip.Job(K, d, helpers.split_path("phys", p), helpers.split_path("par", t), L)
+    try:
+        job.set_reference_file(fa)
+        if sharded:
+            import torch
+            from cora_amd import dist as cdist
+            cdist.ShardedJob(job, cdist.Comm(torch.device("cuda", 0))).run()
+        else:
+            job.run()
+        return job.tables()
+    finally:
+        job.close()
+
+
+def test_ragged_fasta_is_refused(tmp_path):
+    """The reference's loader assumes one line width (HTS:96-142) and silently mis-loads anything else."""
+    rs = np.random.RandomState(1)
+    seq = synth.random_seq(rs, 3000)
+    fa = str(tmp_path / "ragged.fa")
+    synth.write_fasta(fa, [("c1", seq)], 60)
+    text = open(fa).read().split("\n")
+    text[5] = text[5] + text[6][:7]              # one long line, the next one short
+    text[6] = text[6][7:]
+    open(fa, "w").write("\n".join(text))
+    with pytest.raises(hip.CoraHipError) as e:
+        _build(fa, 50, 2)
+    assert e.value.code == 51
+    exe = os.path.join(hip.BIN_DIR, "homTable_setup")
+    r = subprocess.run([exe, fa, "50", helpers.split_path("phys", 1), str(tmp_path / "E"), str(tmp_path / "I"),
+                        helpers.split_path("par", 1), "BOTH", "2", "FULL"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 51, r.stdout
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+@pytest.mark.parametrize("kind", ["all_n", "short", "one_window_at_end"])
+def test_contig_without_a_window_is_refused(kind, sharded, tmp_path):
+    """HTS:2530 reads before its buffer for such a contig; here: status 54, from both entry points."""
+    rs = np.random.RandomState(2)
+    good = synth.random_seq(rs, 4000)
+    bad = {"all_n": synth.seq_from_str("N" * 500),
+           "short": synth.random_seq(rs, 40),
+           "one_window_at_end": np.concatenate([synth.seq_from_str("N" * 100), synth.random_seq(rs, 50)])}[kind]   # Q4: no window
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, [("ok", good), ("bad", bad), ("ok2", synth.random_seq(rs, 2000))], 60)
+    with pytest.raises(hip.CoraHipError) as e:
+        _build(fa, 50, 2, sharded=sharded)
+    assert e.value.code == 54
+
+
+def test_many_contigs_need_the_wide_layout(tmp_path):
+    rs = np.random.RandomState(3)
+    unit = synth.random_seq(rs, 220)
+    contigs = []
+    for c in range(140):                                     # > 127 contigs: 1-byte contig ids do not suffice (cora.cpp:488-493)
+        s = synth.random_seq(rs, 400)
+        if c % 7 == 0:
+            s[50:270] = synth.mutate(rs, unit, 0.01)         # homologies across contigs
+        contigs.append(("c%d" % c, s))
+    fa = str(tmp_path / "many.fa")
+    synth.write_fasta(fa, contigs, 50)
+    with pytest.raises(hip.CoraHipError) as e:
+        _build(fa, 40, 2)
+    assert e.value.code == 19
+    oex, oinx = helpers.run_oracle(fa, 40, 2, helpers.split_path("phys", 2), helpers.split_path("par", 3), str(tmp_path / "o"), L=True)
+    for sharded in (False, True):
+        ex, en, inx, inn = _build(fa, 40, 2, 2, 3, L=True, sharded=sharded)
+        assert ex == helpers.read(oex) and inx == helpers.read(oinx)
+        assert en > 0 and inn > 0
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_reference_without_any_repeat_gives_empty_tables(sharded, tmp_path):
+    fa = str(tmp_path / "u.fa")
+    synth.write_fasta(fa, [("u", synth.random_seq(np.random.RandomState(4), 20000))], 60)
+    oex, oinx = helpers.run_oracle(fa, 60, 1, helpers.split_path("phys", 1), helpers.split_path("par", 1), str(tmp_path / "o"))
+    ex, en, inx, inn = _build(fa, 60, 1, sharded=sharded)
+    assert (ex, inx) == (helpers.read(oex), helpers.read(oinx))
+    assert (en, inn, len(ex), len(inx)) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("K,d", [(36, 3), (50, 2)])
+def test_low_complexity_and_iupac(K, d, tmp_path):
+    """Tandem repeats make classes of thousands of entries, lists far beyond 16 items and runs full of tied targets
+    (the host-finished part of <Inexact>); IUPAC letters and lower case break windows exactly as N / upper case do."""
+    rs = np.random.RandomState(5)
+    parts = [synth.random_seq(rs, 3000), synth.seq_from_str("AT" * 700), synth.random_seq(rs, 500), synth.seq_from_str("A" * 900),
+             synth.random_seq(rs, 800), synth.seq_from_str("ACG" * 400), synth.seq_from_str("RYKM"), synth.random_seq(rs, 2500),
+             synth.seq_from_str("AT" * 300), synth.seq_from_str("n"), synth.random_seq(rs, 1500)]
+    seq = np.concatenate(parts)
+    low = seq.copy()
+    low[1000:1400] = np.frombuffer(bytes(low[1000:1400]).lower(), dtype=np.uint8)
+    fa = str(tmp_path / "lc.fa")
+    synth.write_fasta(fa, [("lc", low), ("rc", synth.revcomp(seq[2000:6200]))], 80)     # ACGT only up to the IUPAC letters
+    oex, oinx = helpers.run_oracle(fa, K, d, helpers.split_path("phys", 4), helpers.split_path("par", 5), str(tmp_path / "o"))
+    for sharded in (False, True):
+        ex, en, inx, inn = _build(fa, K, d, 4, 5, sharded=sharded)
+        assert ex == helpers.read(oex), "Exact differs (sharded=%s)" % sharded
+        assert inx == helpers.read(oinx), "Inexact differs (sharded=%s)" % sharded
+
+
+def test_sharded_stages_at_full_size_match_reference_hash():
+    """The multi-GPU stage functions on bench.py's workload (one rank): same sha256 as the real reference's tables."""
+    import hashlib
+    c = helpers.MANIFEST["cases"]["chr20_like_k50_d2"]
+    contigs = synth.workload_chr20_like(20, 64_000_000)
+    image, W, geom = synth.fasta_image(contigs, 60)
+    import torch
+    from cora_amd import dist as cdist
+    job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]))
+    job.set_reference(image, W, geom)
+    cdist.ShardedJob(job, cdist.Comm(torch.device("cuda", 0))).run()
+    e, en, i, inn = job.tables()
+    assert (en, inn) == (c["exact_nodes"], c["inexact_nodes"])
+    assert hashlib.sha256(e).hexdigest() == c["exact_sha256"] and hashlib.sha256(i).hexdigest() == c["inexact_sha256"]
+    job.close()
