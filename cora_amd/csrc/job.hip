@@ -154,6 +154,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         launch_contig_check(s, dp, x.gp.p, x.N, job->ctr.p);
         DevCounters h;
         RCQ(read_counters(job, h));
+        FORMAT_ERROR_CHECK(h);
         if (h.empty_contigs)
             return fail(54, "%llu contig(s) hold no findable %d-mer: the reference's behaviour is undefined there (HTS:2530)",
                         (unsigned long long)h.empty_contigs, dp.K);

@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -165,6 +166,10 @@ inline int write_counters(cora_hip_job *job, const DevCounters &h)
     HIPQ(hipStreamSynchronize(job->stream));
     return 0;
 }
+
+// zeroes n consecutive 8-byte counters, in stream order (no host round trip)
+#define ZERO_COUNTERS(job, field, n) HIPQ(hipMemsetAsync((char *)(job)->ctr.p + offsetof(DevCounters, field), 0, 8 * (n), (job)->stream))
+#define FORMAT_ERROR_CHECK(h) do { if ((h).format_errors) return fail(51, "FASTA image does not have the fixed line width the reference's loader assumes (%llu misplaced line ends)", (unsigned long long)(h).format_errors); } while (0)
 
 inline int bits_for(u64 G)
 {

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__r
 // fallback flag: the caller then redoes the stage with the full-key sort.
 __global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__restrict__ pk, u64 *__restrict__ rec,
                                                   u32 *__restrict__ gpos, u64 n, int hb, const u32 *__restrict__ mixed_list,
-                                                  u32 n_mixed, DevCounters *ctr)
+                                                  u32 n_mixed, u32 *__restrict__ head_flag, DevCounters *ctr)
 {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t >= n_mixed) return;
@@ -297,7 +297,10 @@ __global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__rest
         while (b >= 0 && (kh[b] > h0 || (kh[b] == h0 && kl[b] > l0))) { r_[b + 1] = r_[b]; g_[b + 1] = g_[b]; kh[b + 1] = kh[b]; kl[b + 1] = kl[b]; b--; }
         r_[b + 1] = r0; g_[b + 1] = g0; kh[b + 1] = h0; kl[b + 1] = l0;
     }
-    for (int k = 0; k < L; k++) { rec[s + k] = r_[k]; gpos[s + k] = g_[k]; }
+    for (int k = 0; k < L; k++) {                         // the run in key order, and its class heads
+        rec[s + k] = r_[k]; gpos[s + k] = g_[k];
+        head_flag[s + k] = (k == 0 || kh[k] != kh[k - 1] || kl[k] != kl[k - 1]) ? 1u : 0u;
+    }
 }
 
 // Full-key path (used when k_mixed_fix gives up): class heads from the sorted 128-bit keys, and the
@@ -1073,10 +1076,10 @@ void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const 
 {
     if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_flag, mixed_list, mixed_cap, ctr);
 }
-void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, const u32 *mixed_list,
+void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u32 *head_flag, const u32 *mixed_list,
                       u32 n_mixed, DevCounters *ctr)
 {
-    if (n_mixed) hipLaunchKernelGGL(k_mixed_fix, dim3((n_mixed + 63) / 64), dim3(64), 0, s, p, pk, rec, gpos, n, hb, mixed_list, n_mixed, ctr);
+    if (n_mixed) hipLaunchKernelGGL(k_mixed_fix, dim3((n_mixed + 63) / 64), dim3(64), 0, s, p, pk, rec, gpos, n, hb, mixed_list, n_mixed, head_flag, ctr);
 }
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
                             u32 *head_flag, u64 *rec)

@@ -68,7 +68,7 @@ void launch_kmer_emit_hashed(hipStream_t s, const DevParams &p, const u64 *pk, c
                              u32 n_blocks, u64 *rec, u32 *gpos);
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
                         u32 *head_flag, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr);
-void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb,
+void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u32 *head_flag,
                       const u32 *mixed_list, u32 n_mixed, DevCounters *ctr);
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
                             u64 n, u32 *head_flag, u64 *rec);

@@ -110,6 +110,7 @@ extern "C" int cora_hip_shard_begin(cora_hip_job *job, int rank, int world)
     launch_contig_scan(job->stream, dp, job->bad.p, job->ctr.p);
     DevCounters h;
     RCQ(read_counters(job, h));
+    FORMAT_ERROR_CHECK(h);
     if (h.empty_contigs)
         return fail(54, "%llu contig(s) hold no findable %d-mer: the reference's behaviour is undefined there (HTS:2530)",
                     (unsigned long long)h.empty_contigs, dp.K);

@@ -12,12 +12,7 @@ int st_pack(cora_hip_job *job)
     zero.first_singleton_key = ~0ull;
     RCQ(write_counters(job, zero));
     launch_pack(job->stream, job->dp, job->raw.p, job->pk.p, job->bad.p, job->ctr.p);
-    DevCounters h;
-    RCQ(read_counters(job, h));
-    if (h.format_errors)
-        return fail(51, "FASTA image does not have the fixed line width the reference's loader assumes (%llu misplaced line ends)",
-                    (unsigned long long)h.format_errors);
-    return 0;
+    return 0;                       // format_errors is looked at with the caller's next read of the counters (FORMAT_ERROR_CHECK)
 }
 
 // hashed records (hash|flags, gpos) of the valid windows of blocks [block_lo, block_lo + n_blocks) of 256 positions
@@ -60,22 +55,17 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     keys.a = x.rec.p; keys.c = x.gp.p; tmp.a = x.trec.p; tmp.c = x.tgp.p;
     if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
     DevCounters h;
-    RCQ(read_counters(job, h));
-    h.n_mixed = 0; h.fallback = 0;
-    RCQ(write_counters(job, h));
+    ZERO_COUNTERS(job, n_mixed, 2);                              // n_mixed, fallback
     launch_same_detect(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, mixed_cap, job->ctr.p);
     RCQ(read_counters(job, h));
     bool fallback = false;
     st.hash_mixed_runs += h.n_mixed;
     if (h.n_mixed > mixed_cap) fallback = true;
     else if (h.n_mixed) {
-        launch_mixed_fix(s, dp, job->pk.p, keys.a, keys.c, N, hb, mixed_list.p, (u32)h.n_mixed, job->ctr.p);
+        // the repair re-orders each such run by key and rewrites its class heads; a run it cannot hold sets the fallback flag
+        launch_mixed_fix(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, (u32)h.n_mixed, job->ctr.p);
         RCQ(read_counters(job, h));
-        h.n_mixed = 0;
-        RCQ(write_counters(job, h));
-        launch_same_detect(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, mixed_cap, job->ctr.p);
-        RCQ(read_counters(job, h));
-        if (h.n_mixed || h.fallback) fallback = true;
+        if (h.fallback) fallback = true;
     }
     x.rec_s = keys.a; x.gp_s = keys.c;
     if (fallback) {                 // a long run of colliding keys: redo on the full 128-bit keys (always exact).
@@ -172,9 +162,7 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
         DBuf<u64> coff, tot;
         RCQ(csize.alloc(n)); RCQ(coff.alloc(n)); RCQ(tot.alloc(1));
         DevCounters h;
-        RCQ(read_counters(job, h));
-        h.emitted_exact = 0;
-        RCQ(write_counters(job, h));
+        ZERO_COUNTERS(job, emitted_exact, 1);
         launch_exact_size(s, cw, ce_s.p, mp.p, (u32)n, csize.p, job->ctr.p);
         if (exclusive_scan_u32_to_u64(s, csize.p, coff.p, n, scr.p, tot.p)) return fail(100, "scan launch failed");
         u64 total = 0;
@@ -297,9 +285,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         if (radix_sort(s, kk, kt, M, 32, 32 + gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
         RCQ(hf.alloc(M)); RCQ(nexcl.alloc(M)); RCQ(scr.alloc(scan_scratch_elems(M))); RCQ(tot.alloc(1)); RCQ(blen.alloc(M));
         DevCounters h;
-        RCQ(read_counters(job, h));
-        h.n_dirty = 0;
-        RCQ(write_counters(job, h));
+        ZERO_COUNTERS(job, n_dirty, 1);
         launch_node_flags(s, kk.a, M, hf.p, job->ctr.p);
         if (exclusive_scan_u32_to_u64(s, hf.p, nexcl.p, M, scr.p, tot.p)) return fail(100, "scan launch failed");
         u64 n_nodes = 0;
@@ -318,9 +304,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         DBuf<u64> run_excl, noff, hidx, hoff, tots;
         RCQ(run_head.alloc(nn)); RCQ(node_tie.alloc(nn)); RCQ(run_dirty.alloc(nn)); RCQ(nsize.alloc(nn)); RCQ(hflag.alloc(nn)); RCQ(hcnt.alloc(nn));
         RCQ(run_excl.alloc(nn)); RCQ(noff.alloc(nn)); RCQ(hidx.alloc(nn)); RCQ(hoff.alloc(nn)); RCQ(tots.alloc(4));
-        RCQ(read_counters(job, h));
-        h.emitted_nodes = 0;
-        RCQ(write_counters(job, h));
+        ZERO_COUNTERS(job, emitted_nodes, 1);
         launch_node_class(s, dp, kk.a, nstart.p, nn, run_head.p, node_tie.p);
         if (exclusive_scan_u32_to_u64(s, run_head.p, run_excl.p, nn, scr.p, nullptr)) return fail(100, "scan launch failed");
         HIPQ(hipMemsetAsync(run_dirty.p, 0, (size_t)nn * sizeof(u32), s));
