@@ -16,7 +16,8 @@ namespace cora {
 
 __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32 *lds_waves /*[4]*/, u32 *total)
 {
-    // 256 threads, one value each; returns the exclusive prefix of v over threadIdx.x
+    // threads 0..255 hold one value each (later threads of a bigger block pass 0 and ignore the result);
+    // returns the exclusive prefix of v over threadIdx.x.  Every thread of the block must call it.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     u32 x = v;
 #pragma unroll
@@ -24,7 +25,7 @@ __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32 *lds_waves /*
         u32 y = __shfl_up(x, o, 64);
         if (lane >= o) x += y;
     }
-    if (lane == 63) lds_waves[wv] = x;
+    if (lane == 63 && wv < 4) lds_waves[wv] = x;
     __syncthreads();
     u32 base = 0, tot = 0;
 #pragma unroll
@@ -34,12 +35,14 @@ __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32 *lds_waves /*
     return base + x - v;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_hist(const u64 *__restrict__ w, u64 n, int shift, u32 mask,
-                                                       u32 *__restrict__ tile_hist)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u64 n, int shift, u32 mask,
+                                                    u32 *__restrict__ tile_hist)
 {
+    constexpr int RS_THREADS = THREADS, RS_TILE = THREADS * RS_IPT;
     __shared__ u32 h[256];
     const int tid = threadIdx.x;
-    h[tid] = 0;
+    if (tid < 256) h[tid] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * RS_TILE;
     if (base + RS_TILE <= n && ((size_t)w & 15) == 0) { // whole tile: 16-byte loads, two records each (order is irrelevant here)
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist(const u64 *__restrict__ w,
         }
     }
     __syncthreads();
-    tile_hist[(size_t)blockIdx.x * 256 + tid] = h[tid];
+    if (tid < 256) tile_hist[(size_t)blockIdx.x * 256 + tid] = h[tid];
 }
 
 // Offsets: the run of digit d of tile t starts at  sum of all counts of digits < d  +  counts of d in tiles < t.
@@ -156,14 +159,15 @@ __global__ __launch_bounds__(256) void rs_colscan(u32 *tile_hist, u32 tiles, con
 // The scatter.  Thread (wave w, lane l) owns records base + w*64*IPT + r*64 + l, r = 0..IPT-1,
 // so that (wave, round, lane) order is the input order: ranks assigned in that order keep
 // the sort stable.
-template <bool HAS_B, bool HAS_C, bool DIG_B>
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__ a_in, const u64 *__restrict__ b_in,
+template <bool HAS_B, bool HAS_C, bool DIG_B, int THREADS>
+__global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_in, const u64 *__restrict__ b_in,
                                                           const u32 *__restrict__ c_in, u64 *__restrict__ a_out,
                                                           u64 *__restrict__ b_out, u32 *__restrict__ c_out, u64 n,
                                                           int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg)
 {
-    __shared__ u64 stage[RS_TILE];          // 32 KiB
-    __shared__ u32 wcnt[4][256];            // per-wave digit counters, then per-wave digit bases
+    constexpr int RS_THREADS = THREADS, RS_TILE = THREADS * RS_IPT, RS_WAVES = THREADS / 64;
+    __shared__ u64 stage[RS_TILE];          // 8 B per record of the tile
+    __shared__ u32 wcnt[RS_WAVES][256];            // per-wave digit counters, then per-wave digit bases
     __shared__ u32 delta[256];              // global offset of the digit's run minus its local start
     __shared__ u32 wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -198,8 +202,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__
             cv[r] = (li < count) ? c_in[base + li] : 0;
         }
     }
-#pragma unroll
-    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
+    for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0;
     __syncthreads();
 
     u32 lpos[RS_IPT];
@@ -226,10 +229,18 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__
     }
     __syncthreads();
     {
-        const u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-        const u32 start = block_exclusive_scan_256(c0 + c1 + c2 + c3, wsum, nullptr);
-        wcnt[0][tid] = start; wcnt[1][tid] = start + c0; wcnt[2][tid] = start + c0 + c1; wcnt[3][tid] = start + c0 + c1 + c2;
-        delta[tid] = tile_off[(size_t)tile * 256 + tid] - start;
+        // threads 0..255 own one digit each: per-wave counts -> per-wave starts inside the tile
+        const int dg = tid & 255;
+        u32 c[RS_WAVES], tot = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { c[w] = wcnt[w][dg]; tot += c[w]; }
+        const u32 start = block_exclusive_scan_256(tid < 256 ? tot : 0u, wsum, nullptr);
+        if (tid < 256) {
+            u32 run = start;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; w++) { wcnt[w][dg] = run; run += c[w]; }
+            delta[tid] = tile_off[(size_t)tile * 256 + tid] - start;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const u64 *__restrict__
 
 int SortScratch::reserve(u64 n)
 {
-    size_t tiles = (size_t)((n + RS_TILE - 1) / RS_TILE);
+    size_t tiles = (size_t)((n + RS_TILE_MIN - 1) / RS_TILE_MIN);
     size_t chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
     if (tiles > cap_tiles) {
         if (tile_hist) (void)hipFree(tile_hist);
@@ -320,10 +331,10 @@ static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArray
                            int shift, u32 mask, const u32 *tile_off, u32 xg)
 {
     if (HAS_B && dig_b)
-        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true>), dim3(tiles), dim3(RS_THREADS), 0, s, in.a, in.b, in.c, out.a, out.b,
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, (HAS_C ? 512 : 256)>), dim3(tiles), dim3(HAS_C ? 512 : 256), 0, s, in.a, in.b, in.c, out.a, out.b,
                            out.c, n, shift, mask, tile_off, xg);
     else
-        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false>), dim3(tiles), dim3(RS_THREADS), 0, s, in.a, in.b, in.c, out.a, out.b,
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, (HAS_C ? 512 : 256)>), dim3(tiles), dim3(HAS_C ? 512 : 256), 0, s, in.a, in.b, in.c, out.a, out.b,
                            out.c, n, shift, mask, tile_off, xg);
 }
 
@@ -338,7 +349,10 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     int pass = 0;
     int rc = scratch.reserve(n);
     if (rc) return rc;
-    const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
+    // records with a payload go through 512-thread tiles of 8192 (their 4-byte payload runs are twice as long: +9 % scatter
+    // bandwidth), key-only records through 256-thread tiles of 4096 (measured best for each, tools/sortbench.cpp)
+    const u32 tile_recs = (keys.c != nullptr) ? 512 * RS_IPT : 256 * RS_IPT;
+    const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
     const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
     const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
     const u64 rec_bytes = 8 + (has_b ? 8 : 0) + (has_c ? 4 : 0);
@@ -348,7 +362,8 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const bool dig_b = has_b && bit < 64;
         const int shift = has_b ? (bit & 63) : bit;
         const u64 *word = dig_b ? keys.b : keys.a;
-        hipLaunchKernelGGL(rs_hist, dim3(tiles), dim3(RS_THREADS), 0, s, word, n, shift, mask, scratch.tile_hist);
+        if (has_c) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, scratch.tile_hist);
+        else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, scratch.tile_hist);
         hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, scratch.chunk_sums);
         u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
         hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);

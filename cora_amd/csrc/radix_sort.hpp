@@ -37,9 +37,9 @@ struct SortScratch {
 };
 
 constexpr int RS_MAX_PASSES = 16;
-constexpr int RS_THREADS = 256;
+constexpr int RS_THREADS = 256;                   // smallest workgroup of the sort kernels (see radix_sort())
 constexpr int RS_IPT = 16;
-constexpr int RS_TILE = RS_THREADS * RS_IPT;      // 4096 records per workgroup
+constexpr int RS_TILE_MIN = RS_THREADS * RS_IPT;  // 4096 records: the smallest tile
 constexpr int RS_CHUNK_TILES = 64;                // tiles per column-scan workgroup
 
 // Sorts n records by key bits [bit_lo, bit_hi) (bit 0 = LSB of the logical key,
