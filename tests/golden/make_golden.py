@@ -205,7 +205,7 @@ INPUTS = {
 # inputs too big to commit are rebuilt from the recipe by the tests (sha256 pinned)
 RECIPE_ONLY = {"ecoli_like", "chr20_like"}
 # cases whose tables are too big to commit: only their sha256 and sizes are pinned
-HASH_ONLY = {"chr20_like_k50_d2"}
+HASH_ONLY = {"chr20_like_k50_d2", "chr20_like_k50_d3"}
 
 #        case name        input   K   d  p   t  L
 CASES = [
@@ -230,6 +230,8 @@ CASES = [
     ("fam_k48_d3",        "fam",  48, 3, 2,  2, 0),
     ("ecoli_like_k50_d2", "ecoli_like", 50, 2, 1, 8, 0),
     ("chr20_like_k50_d2", "chr20_like", 50, 2, 1, 8, 0),
+    # d = 3 on a contig longer than 50 Mbp: the window-by-window compaction (HTS:1467-1581), with cora's default -p 10 -t 8
+    ("chr20_like_k50_d3", "chr20_like", 50, 3, 10, 8, 0),
 ]
 
 

@@ -134,3 +134,42 @@ def test_sharded_stages_at_full_size_match_reference_hash():
     assert (en, inn) == (c["exact_nodes"], c["inexact_nodes"])
     assert hashlib.sha256(e).hexdigest() == c["exact_sha256"] and hashlib.sha256(i).hexdigest() == c["inexact_sha256"]
     job.close()
+
+
+def test_large_reference_is_semantically_consistent(tmp_path):
+    """A 170 Mbp, three-contig reference: more than 2**27 K-mers, so the exact stage sorts on the 56-bit hash prefix
+    (7 passes), and far beyond what the oracle can restate in test time.  Every record of both tables is checked
+    against the bases by oracle/table_check (itself pinned on the real reference's tables, tests/test_table_check.py);
+    plain run, sharded stages and a second plain run must give the same bytes."""
+    import hashlib
+    import subprocess
+    check = os.path.join(helpers.ORACLE_DIR, "table_check")
+    if not os.path.exists(check):
+        subprocess.check_call(["make", "-C", helpers.ORACLE_DIR, "table_check"], stdout=subprocess.DEVNULL)
+    contigs = [("big%d" % c, synth.workload_chr20_like(70 + c, n)[0][1]) for c, n in enumerate((90_000_000, 50_000_000, 30_000_000))]
+    fa = str(tmp_path / "big.fa")
+    synth.write_fasta(fa, contigs, 60)
+    del contigs
+    job = hip.Job(50, 2, helpers.split_path("phys", 10), helpers.split_path("par", 8))
+    job.set_reference_file(fa)
+    job.run()
+    ex, en, inx, inn = job.tables()
+    st = job.stats()
+    assert st["kmers"] > (1 << 27) and st["full_key_fallback"] == 0
+    ep, ip = str(tmp_path / "Exact"), str(tmp_path / "Inexact")
+    open(ep, "wb").write(ex); open(ip, "wb").write(inx)
+    open(ep + ".itemCount", "w").write("%d\n" % en); open(ip + ".itemCount", "w").write("%d\n" % inn)
+    r = subprocess.run([check, fa, "50", "2", ep, ip], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert en > 50_000 and inn > 500_000, (en, inn, r.stdout)
+    sha = (hashlib.sha256(ex).hexdigest(), hashlib.sha256(inx).hexdigest())
+    del ex, inx
+    import torch
+    from cora_amd import dist as cdist
+    cdist.ShardedJob(job, cdist.Comm(torch.device("cuda", 0))).run()
+    e2, en2, i2, inn2 = job.tables()
+    assert (hashlib.sha256(e2).hexdigest(), hashlib.sha256(i2).hexdigest(), en2, inn2) == sha + (en, inn)
+    job.run()
+    e3, _, i3, _ = job.tables()
+    assert (hashlib.sha256(e3).hexdigest(), hashlib.sha256(i3).hexdigest()) == sha
+    job.close()
