@@ -192,14 +192,14 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
         u32 li = l0 + r * 64;
-        kw[r] = (li < count) ? dig_in[base + li] : 0;
+        kw[r] = (li < count) ? __builtin_nontemporal_load(dig_in + base + li) : 0;
     }
     u32 cv[HAS_C ? RS_IPT : 1];             // the payload is fetched now, beside the keys, and staged after them
     if (HAS_C) {
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            cv[r] = (li < count) ? c_in[base + li] : 0;
+            cv[r] = (li < count) ? __builtin_nontemporal_load(c_in + base + li) : 0;
         }
     }
     for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0;

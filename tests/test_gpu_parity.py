@@ -179,11 +179,14 @@ def test_hash_collisions_are_repaired(name, bits, expect, monkeypatch):
 
 
 # ------------------------------------------------------------------ the benchmark workload at full size
-def test_full_size_workload_matches_reference_hash():
-    """bench.py's N=1 workload (64 Mbp chr20_like, K=50, d=2): the real reference's tables for it are pinned
-    by sha256 in the manifest (made by tests/golden/make_golden.py; too big to commit)."""
+@pytest.mark.parametrize("name", ["chr20_like_k50_d2", "chr20_like_k50_d3"])
+def test_full_size_workload_matches_reference_hash(name):
+    """bench.py's N=1 workload (64 Mbp chr20_like, K=50): the real reference's tables for it are pinned by sha256 in
+    the manifest (made by tests/golden/make_golden.py; too big to commit).  d=2 with -p 1 is the bench configuration;
+    d=3 with cora's default -p 10 -t 8 is the only case in which the reference compacts <Inexact> in 50 Mbp windows
+    (HTS:1467-1581: d = 3 and a contig longer than 50 Mbp; 3.5 minutes of the reference on 8 cores)."""
     import hashlib
-    c = helpers.MANIFEST["cases"]["chr20_like_k50_d2"]
+    c = helpers.MANIFEST["cases"][name]
     contigs = synth.workload_chr20_like(20, 64_000_000)
     image, W, geom = synth.fasta_image(contigs, 60)
     assert hashlib.sha256(image.tobytes()).hexdigest() == helpers.MANIFEST["inputs"]["chr20_like"]["sha256"]
