@@ -49,7 +49,7 @@ __global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u6
         const ulonglong2 *w2 = reinterpret_cast<const ulonglong2 *>(w + base);
         ulonglong2 v[RS_IPT / 2];
 #pragma unroll
-        for (int k = 0; k < RS_IPT / 2; k++) v[k] = w2[k * RS_THREADS + tid];
+        for (int k = 0; k < RS_IPT / 2; k++) { v[k].x = __builtin_nontemporal_load(&w2[k * RS_THREADS + tid].x); v[k].y = __builtin_nontemporal_load(&w2[k * RS_THREADS + tid].y); }
 #pragma unroll
         for (int k = 0; k < RS_IPT / 2; k++) {
             atomicAdd(&h[(u32)(v[k].x >> shift) & mask], 1u);
