@@ -179,11 +179,20 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     // ---- stage 3: per seed: codes, sort, equal runs, verification (HTS:2671-2800, 2138-2265) ----
     PairStore ps;
     {
-        DBuf<u64> codes;
-        RCQ(codes.alloc(NR));
+        // every seed's codes in one pass over the representatives, each with its first-digit tile histogram
+        DBuf<u64> codes[CORA_HIP_MAX_SEEDS];
+        DBuf<u32> hists[CORA_HIP_MAX_SEEDS];
+        u64 *cp[4] = {nullptr, nullptr, nullptr, nullptr};
+        u32 *hp[4] = {nullptr, nullptr, nullptr, nullptr};
+        const u64 tiles = (NR + RS_TILE_MIN - 1) / RS_TILE_MIN;
+        for (int q = 0; q < dp.nseeds; q++) {
+            RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
+            cp[q] = codes[q].p; hp[q] = hists[q].p;
+        }
+        launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp);
         for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
-            launch_seed_codes(s, dp, job->pk.p, reps.p, NR, seed, codes.p);
-            RCQ(st_seed_verify(job, codes, NR, seed, ps));
+            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p));
+            codes[seed - 1].release(); hists[seed - 1].release();
         }
         st.hom_pairs = ps.n;
     }

@@ -591,6 +591,43 @@ __global__ __launch_bounds__(256) void k_seed_codes(DevParams p, const u64 *__re
     out[r] = ((u64)(fw <= rc ? fw : rc) << 32) | g;          // canonical code (HTS:2732-2744)
 }
 
+// All seeds of a run in one pass over the representatives: one window load, NS codes, and -- because a block covers
+// exactly one 4096-record tile of the key-only sort -- the per-tile histogram of each code array's first sort digit
+// (bits 32..39 of the record = low byte of the code), which saves that sort its first histogram pass.
+template <int NS>
+__global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ reps, u64 n_reps,
+                                                        u64 *__restrict__ out0, u64 *__restrict__ out1, u64 *__restrict__ out2,
+                                                        u64 *__restrict__ out3, u32 *__restrict__ hist0, u32 *__restrict__ hist1,
+                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3)
+{
+    __shared__ u32 h[NS][256];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < NS; s++) h[s][tid] = 0;
+    __syncthreads();
+    u64 *const outs[4] = {out0, out1, out2, out3};
+    const u64 base = (u64)blockIdx.x * 4096;
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        const u64 r = base + (u64)k * 256 + tid;
+        if (r >= n_reps) break;
+        const u32 g = reps[r];
+        u64 hi, lo;
+        load_window(p, pk, g, hi, lo);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const u32 fw = seed_code(p, hi, lo, s + 1), rc = rc_code(fw);
+            const u32 c = fw <= rc ? fw : rc;
+            outs[s][r] = ((u64)c << 32) | g;
+            atomicAdd(&h[s][c & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    u32 *const hists[4] = {hist0, hist1, hist2, hist3};
+#pragma unroll
+    for (int s = 0; s < NS; s++) hists[s][(size_t)blockIdx.x * 256 + tid] = h[s][tid];
+}
+
 struct Mism { u64 hi, lo; };
 __device__ __forceinline__ Mism mism_of(u64 ah, u64 al, u64 bh, u64 bl)
 {
@@ -1133,6 +1170,16 @@ void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls
 void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out)
 {
     if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
+}
+void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4])
+{
+    if (!n_reps) return;
+    const dim3 g((unsigned)((n_reps + 4095) / 4096));
+    switch (p.nseeds) {
+    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3]); break;
+    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3]); break;
+    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3]); break;
+    }
 }
 void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active)
 {

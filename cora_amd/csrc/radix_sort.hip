@@ -339,7 +339,7 @@ static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArray
 }
 
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi, SortScratch &scratch,
-               SortTiming *timing)
+               SortTiming *timing, u32 *first_hist)
 {
     if (n == 0 || bit_hi <= bit_lo) return 0;
     if (n >= (1ull << 32)) return (int)hipErrorInvalidValue;      // u32 offsets inside the kernels
@@ -362,19 +362,21 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const bool dig_b = has_b && bit < 64;
         const int shift = has_b ? (bit & 63) : bit;
         const u64 *word = dig_b ? keys.b : keys.a;
-        if (has_c) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, scratch.tile_hist);
-        else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, scratch.tile_hist);
-        hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, scratch.chunk_sums);
+        u32 *th = scratch.tile_hist;
+        if (pass == 0 && first_hist && !has_b && !has_c) th = first_hist;          // the producer already counted this digit
+        else if (has_c) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th);
+        else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th);
+        hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums);
         u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
         hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);
-        hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, scratch.tile_hist, tiles, chunk_off);
+        hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, th, tiles, chunk_off);
         if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass], s));
         if (has_b) {
-            if (has_c) launch_scatter<true, true>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
-            else launch_scatter<true, false>(s, dig_b, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
+            if (has_c) launch_scatter<true, true>(s, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
+            else launch_scatter<true, false>(s, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
         } else {
-            if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
-            else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, shift, mask, scratch.tile_hist, scratch.xcd_group);
+            if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
+            else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
         }
         if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass + 1], s));
         SortArrays t = keys; keys = tmp; tmp = t;

@@ -46,8 +46,10 @@ constexpr int RS_CHUNK_TILES = 64;                // tiles per column-scan workg
 // bit_lo is rounded down to a multiple of 8).  Stable.  `keys` and `tmp` are
 // ping-pong buffers of equal shape; on return `keys` names the sorted data
 // (the two structs are swapped after an odd number of passes).
+// first_hist (optional, key-only records): the [tiles of RS_TILE_MIN][256] histogram of the first pass's digit, already
+// computed by whoever produced the records; it is consumed (turned into offsets in place).
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi,
-               SortScratch &scratch, SortTiming *timing);
+               SortScratch &scratch, SortTiming *timing, u32 *first_hist = nullptr);
 
 // out[i] = sum_{j<i} in[j]  (u32 in, u64 out); *total_dev (device u64) gets the grand total.
 // scratch_dev must hold at least scan_scratch_elems(n) u64.

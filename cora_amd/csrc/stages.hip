@@ -211,7 +211,7 @@ int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBu
 
 // One seed: sort the (code, position) records, compact the run members, verify, append the pair records
 // (HTS:2671-2800, 2138-2265).  codes holds n records in which equal codes appear in increasing position.
-int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps)
+int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
@@ -223,7 +223,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     RCQ(scr.alloc(scan_scratch_elems(vb))); RCQ(tots.alloc(2));
     SortArrays ck, ct;
     ck.a = codes.p; ct.a = codes_tmp.p;
-    if (radix_sort(s, ck, ct, n, 32, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+    if (radix_sort(s, ck, ct, n, 32, 64, job->sort_scratch, &job->sort_timing, first_hist)) return fail(100, "radix sort failed");
     launch_active_count(s, ck.a, n, blk_active.p);
     if (exclusive_scan_u32_to_u64(s, blk_active.p, blk_off.p, vb, scr.p, tots.p)) return fail(100, "scan launch failed");
     u64 n_active = 0;
