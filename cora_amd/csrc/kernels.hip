@@ -468,6 +468,33 @@ __global__ __launch_bounds__(256) void k_class_emit(const u64 *__restrict__ rec,
     }
 }
 
+// ------------------------------------------------------------------ flags -> positions of the set flags
+// (two light passes and a scan over the per-block counts instead of a full-length prefix sum)
+__global__ __launch_bounds__(256) void k_flag_count(const u32 *__restrict__ flag, u64 n, u32 *__restrict__ blk_count)
+{
+    __shared__ u32 ws[4];
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 bal = __ballot(i < n && flag[i] != 0);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void k_flag_emit(const u32 *__restrict__ flag, u64 n, const u64 *__restrict__ blk_off, u32 *__restrict__ pos)
+{
+    __shared__ u32 ws[4];
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool set = i < n && flag[i] != 0;
+    const u64 bal = __ballot(set);
+    if (lane == 0) ws[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    if (!set) return;
+    u32 pre = 0;
+    for (int w = 0; w < wv; w++) pre += ws[w];
+    pos[blk_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = (u32)i;
+}
+
 // ------------------------------------------------------------------ bitmap -> sorted position list
 __global__ __launch_bounds__(256) void k_bitmap_count(const u32 *__restrict__ bits, u64 n_words, u32 *__restrict__ block_counts)
 {
@@ -1143,6 +1170,14 @@ void launch_nonrep_mark(hipStream_t s, const u32 *head_flag, const u32 *gpos, u6
 void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep)
 {
     hipLaunchKernelGGL(k_rep_mask, grid_for(p.G), dim3(256), 0, s, p, bad, nonrep, rep);
+}
+void launch_flag_count(hipStream_t s, const u32 *flag, u64 n, u32 *blk_count)
+{
+    if (n) hipLaunchKernelGGL(k_flag_count, grid_for(n), dim3(256), 0, s, flag, n, blk_count);
+}
+void launch_flag_emit(hipStream_t s, const u32 *flag, u64 n, const u64 *blk_off, u32 *pos)
+{
+    if (n) hipLaunchKernelGGL(k_flag_emit, grid_for(n), dim3(256), 0, s, flag, n, blk_off, pos);
 }
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks)
 {

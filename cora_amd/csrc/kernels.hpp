@@ -78,6 +78,8 @@ void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32
                        u64 *cls /* rep<<32 | class index */, const u64 *nons_off);
 void launch_nonrep_mark(hipStream_t s, const u32 *head_flag, const u32 *gpos, u64 n, u32 *nonrep);
 void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep /* may alias nonrep */);
+void launch_flag_count(hipStream_t s, const u32 *flag, u64 n, u32 *blk_count /* [ceil(n/256)] */);
+void launch_flag_emit(hipStream_t s, const u32 *flag, u64 n, const u64 *blk_off, u32 *pos);
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks);
 void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out, u32 base);
 void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,

@@ -85,17 +85,23 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     RCQ(x.nonrep.alloc(dp.n_words));
     HIPQ(hipMemsetAsync(x.nonrep.p, 0, dp.n_words * sizeof(u32), s));
     launch_nonrep_mark(s, head_flag.p, x.gp_s, N, x.nonrep.p);
-    // class index of every record, class starts
-    DBuf<u64> cid, scr0, tot0;
-    RCQ(cid.alloc(N)); RCQ(scr0.alloc(scan_scratch_elems(N))); RCQ(tot0.alloc(1));
-    if (exclusive_scan_u32_to_u64(s, head_flag.p, cid.p, N, scr0.p, tot0.p)) return fail(100, "scan launch failed");
-    HIPQ(hipMemcpyAsync(&x.NR, tot0.p, sizeof x.NR, hipMemcpyDeviceToHost, s));
-    HIPQ(hipStreamSynchronize(s));
-    RCQ(x.class_start.alloc(x.NR + 1));
-    launch_node_starts(s, head_flag.p, cid.p, N, x.class_start.p);
-    const u32 n32 = (u32)N;
-    HIPQ(hipMemcpyAsync(x.class_start.p + x.NR, &n32, sizeof(u32), hipMemcpyHostToDevice, s));
-    cid.release(); scr0.release(); head_flag.release();
+    // class starts = positions of the head flags
+    {
+        const u64 nb = (N + 255) / 256;
+        DBuf<u32> bcnt;
+        DBuf<u64> boff, scr0, tot0;
+        RCQ(bcnt.alloc(nb)); RCQ(boff.alloc(nb)); RCQ(scr0.alloc(scan_scratch_elems(nb))); RCQ(tot0.alloc(1));
+        launch_flag_count(s, head_flag.p, N, bcnt.p);
+        if (exclusive_scan_u32_to_u64(s, bcnt.p, boff.p, nb, scr0.p, tot0.p)) return fail(100, "scan launch failed");
+        HIPQ(hipMemcpyAsync(&x.NR, tot0.p, sizeof x.NR, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        RCQ(x.class_start.alloc(x.NR + 1));
+        launch_flag_emit(s, head_flag.p, N, boff.p, x.class_start.p);
+        const u32 n32 = (u32)N;
+        HIPQ(hipMemcpyAsync(x.class_start.p + x.NR, &n32, sizeof(u32), hipMemcpyHostToDevice, s));
+        HIPQ(hipStreamSynchronize(s));          // n32 lives on this frame
+    }
+    head_flag.release();
 
     const u32 kb = (u32)((x.NR + 255) / 256);
     DBuf<u32> blk_nons;
