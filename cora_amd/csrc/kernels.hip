@@ -690,7 +690,8 @@ __device__ __forceinline__ u32 judge(const DevParams &p, Mism m, int seed, u32 d
 // its first, plus every record with a palindromic code (it meets itself, Q1).  On a random genome that is
 // about 1.5 % of the records, one per wave: the verification kernels therefore run over the compacted list
 // of such records (all 64 lanes busy with gathers) instead of over all records.
-__global__ __launch_bounds__(256) void k_active_count(const u64 *__restrict__ codes, u64 n_reps, u32 *__restrict__ blk_active)
+__global__ __launch_bounds__(256) void k_active_count(const u64 *__restrict__ codes, u64 n_reps, u32 *__restrict__ blk_active,
+                                                      u64 *__restrict__ act_mask)
 {
     __shared__ u32 ws[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -700,28 +701,23 @@ __global__ __launch_bounds__(256) void k_active_count(const u64 *__restrict__ co
         act = (i > 0 && (u32)(codes[i - 1] >> 32) == code) || rc_code(code) == code;
     }
     const u64 bal = __ballot(act);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (u32)__popcll(bal);
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = (u32)__popcll(bal); act_mask[i >> 6] = bal; }   // one word per wave
     __syncthreads();
     if (threadIdx.x == 0) blk_active[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-__global__ __launch_bounds__(256) void k_active_emit(const u64 *__restrict__ codes, u64 n_reps, const u64 *__restrict__ blk_off,
+// second pass: positions of the set bits, from the wave masks alone (the codes are not read again)
+__global__ __launch_bounds__(256) void k_active_emit(const u64 *__restrict__ act_mask, u64 n_reps, const u64 *__restrict__ blk_off,
                                                      u32 *__restrict__ active)
 {
-    __shared__ u32 ws[4];
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    bool act = false;
-    if (i < n_reps) {
-        const u32 code = (u32)(codes[i] >> 32);
-        act = (i > 0 && (u32)(codes[i - 1] >> 32) == code) || rc_code(code) == code;
-    }
-    const u64 bal = __ballot(act);
-    if (lane == 0) ws[wv] = (u32)__popcll(bal);
-    __syncthreads();
-    if (!act) return;
+    const u64 w0 = (u64)blockIdx.x * 4;
+    const u64 n_words = (n_reps + 63) >> 6;
+    const u64 bal = (w0 + wv < n_words) ? act_mask[w0 + wv] : 0;
+    if (!((bal >> lane) & 1ull)) return;
     u32 pre = 0;
-    for (int w = 0; w < wv; w++) pre += ws[w];
+    for (int w = 0; w < wv; w++) pre += (u32)__popcll(act_mask[w0 + w]);
     active[blk_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = (u32)i;
 }
 
@@ -1216,13 +1212,13 @@ void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, con
     default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3]); break;
     }
 }
-void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active)
+void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active, u64 *act_mask)
 {
-    if (n_reps) hipLaunchKernelGGL(k_active_count, grid_for(n_reps), dim3(256), 0, s, codes, n_reps, blk_active);
+    if (n_reps) hipLaunchKernelGGL(k_active_count, grid_for(n_reps), dim3(256), 0, s, codes, n_reps, blk_active, act_mask);
 }
-void launch_active_emit(hipStream_t s, const u64 *codes, u64 n_reps, const u64 *blk_off, u32 *active)
+void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u64 *blk_off, u32 *active)
 {
-    if (n_reps) hipLaunchKernelGGL(k_active_emit, grid_for(n_reps), dim3(256), 0, s, codes, n_reps, blk_off, active);
+    if (n_reps) hipLaunchKernelGGL(k_active_emit, grid_for(n_reps), dim3(256), 0, s, act_mask, n_reps, blk_off, active);
 }
 void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
                          u32 *cnt_recs, u32 *cnt_cand)

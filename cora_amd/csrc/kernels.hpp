@@ -91,8 +91,8 @@ void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls
 void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out);
 // every seed's (code, position) records at once + the first-digit tile histogram of each (tiles of 4096 records)
 void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4]);
-void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active);
-void launch_active_emit(hipStream_t s, const u64 *codes, u64 n_reps, const u64 *blk_off, u32 *active);
+void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active, u64 *act_mask /* [ceil(n/256)*4] */);
+void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u64 *blk_off, u32 *active);
 void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,
                          int seed, u32 *cnt_recs, u32 *cnt_cand);
 void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,

@@ -225,12 +225,13 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     DBuf<u64> codes_tmp, blk_off, scr, tots;
     DBuf<u32> blk_active;
     const u32 vb = (u32)((n + 255) / 256);
-    RCQ(codes_tmp.alloc(n)); RCQ(blk_active.alloc(vb)); RCQ(blk_off.alloc(vb));
+    DBuf<u64> act_mask;
+    RCQ(codes_tmp.alloc(n)); RCQ(blk_active.alloc(vb)); RCQ(blk_off.alloc(vb)); RCQ(act_mask.alloc((u64)vb * 4));
     RCQ(scr.alloc(scan_scratch_elems(vb))); RCQ(tots.alloc(2));
     SortArrays ck, ct;
     ck.a = codes.p; ct.a = codes_tmp.p;
     if (radix_sort(s, ck, ct, n, 32, 64, job->sort_scratch, &job->sort_timing, first_hist)) return fail(100, "radix sort failed");
-    launch_active_count(s, ck.a, n, blk_active.p);
+    launch_active_count(s, ck.a, n, blk_active.p, act_mask.p);
     if (exclusive_scan_u32_to_u64(s, blk_active.p, blk_off.p, vb, scr.p, tots.p)) return fail(100, "scan launch failed");
     u64 n_active = 0;
     HIPQ(hipMemcpyAsync(&n_active, tots.p, sizeof n_active, hipMemcpyDeviceToHost, s));
@@ -241,7 +242,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     DBuf<u64> rec_off, cand_off, scr_a;
     RCQ(active.alloc(n_active)); RCQ(cnt_recs.alloc(n_active)); RCQ(cnt_cand.alloc(n_active));
     RCQ(rec_off.alloc(n_active)); RCQ(cand_off.alloc(n_active)); RCQ(scr_a.alloc(scan_scratch_elems(n_active)));
-    launch_active_emit(s, ck.a, n, blk_off.p, active.p);
+    launch_active_emit(s, act_mask.p, n, blk_off.p, active.p);
     launch_verify_count(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, cnt_recs.p, cnt_cand.p);
     if (exclusive_scan_u32_to_u64(s, cnt_recs.p, rec_off.p, n_active, scr_a.p, tots.p)) return fail(100, "scan launch failed");
     if (exclusive_scan_u32_to_u64(s, cnt_cand.p, cand_off.p, n_active, scr_a.p, tots.p + 1)) return fail(100, "scan launch failed");
