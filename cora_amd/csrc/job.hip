@@ -122,6 +122,7 @@ extern "C" int cora_hip_job_set_reference(cora_hip_job *job, const uint8_t *imag
     dp.ctg_gstart = job->d_gstart.p; dp.ctg_len = job->d_len.p; dp.ctg_off = job->d_off.p; dp.ctg_window = job->d_window.p;
     RCQ(job->pk.alloc(dp.n_words + 4));
     RCQ(job->bad.alloc(dp.n_words + 4));
+    RCQ(job->valid.alloc(dp.n_words + 12));
     RCQ(job->ctr.alloc(1));
     HIPQ(hipStreamSynchronize(job->stream));
     job->have_ref = true;
@@ -167,7 +168,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     {
         RCQ(st_exact_classes(job, x));
         st.representatives = x.NR; st.exact_classes = x.NNS;
-        launch_rep_mask(s, dp, job->bad.p, x.nonrep.p, x.nonrep.p);        // in place: now the representative bitmap
+        launch_rep_mask_words(s, job->valid.p, x.nonrep.p, x.nonrep.p, dp.n_words);   // in place: now the representative bitmap
         RCQ(st_reps(job, x.nonrep.p, 0, dp.n_words, reps, NR));
         ExactParts parts;
         RCQ(st_exact_parts(job, x, parts));

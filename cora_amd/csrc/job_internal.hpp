@@ -138,6 +138,7 @@ struct cora_hip_job {
     DBuf<u32> d_len, d_window;
     DBuf<u64> pk;
     DBuf<u32> bad;
+    DBuf<u32> valid;              // window-validity bitmap of the positions k_kmer_count has covered in this run
     DBuf<DevCounters> ctr;
     SortScratch sort_scratch;
     SortTiming sort_timing;

@@ -149,13 +149,17 @@ __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict_
 }
 
 // ------------------------------------------------------------------ valid windows -> keys
-__global__ __launch_bounds__(256) void k_kmer_count(DevParams p, const u32 *__restrict__ bad, u32 *__restrict__ block_counts)
+__global__ __launch_bounds__(256) void k_kmer_count(DevParams p, const u32 *__restrict__ bad, u32 *__restrict__ block_counts,
+                                                    u32 *__restrict__ valid)
 {
     __shared__ u32 wsum[4];
     const u64 g = p.pos_base + (u64)blockIdx.x * 256 + threadIdx.x;
     const bool ok = (g < p.G) && window_ok(p, bad, g);
     const u64 bal = __ballot(ok);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
+    // the window-validity bitmap (bit 31-i of word w = position 32w+i), kept for the later passes over positions
+    if (valid && (lane == 0 || lane == 32)) valid[g >> 5] = __brev((u32)(bal >> lane));
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
@@ -223,14 +227,14 @@ __device__ __forceinline__ void canonical_at(const DevParams &p, const u64 *__re
 // Hashed record of every valid window: rec = (hash of the canonical key & ~0xFF) | flags, plus gpos.
 // Sorting 12-byte records on the top 48/56 hash bits replaces the 13-pass sort of 20-byte full keys;
 // equal keys have equal hashes, and k_same_detect / k_mixed_fix make the grouping exact.
-__global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ bad,
+__global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ valid,
                                                           const u64 *__restrict__ block_off, u64 *__restrict__ rec,
                                                           u32 *__restrict__ gpos)
 {
     __shared__ u32 wsum[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u64 g = p.pos_base + (u64)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = (g < p.G) && window_ok(p, bad, g);
+    const bool ok = (valid[g >> 5] >> (31 - (g & 31))) & 1u;          // written by k_kmer_count over the same blocks
     const u64 bal = __ballot(ok);
     if (lane == 0) wsum[wv] = (u32)__popcll(bal);
     __syncthreads();
@@ -427,6 +431,13 @@ __global__ __launch_bounds__(256) void k_nonrep_mark(const u32 *__restrict__ hea
     if (i >= n || head_flag[i]) return;
     const u32 g = gpos[i];
     atomicOr(&nonrep[g >> 5], 1u << (31 - (g & 31)));
+}
+
+// the same from the stored window-validity bitmap (single-GPU run: k_kmer_count covered every position)
+__global__ __launch_bounds__(256) void k_rep_mask_words(const u32 *__restrict__ valid, const u32 *nonrep, u32 *rep, u64 n_words)
+{
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w < n_words) rep[w] = valid[w] & ~nonrep[w];
 }
 
 // rep[w] = valid windows of positions 32w..32w+31 (bit 31-i = position 32w+i) minus nonrep[w]; rep may alias nonrep
@@ -706,19 +717,22 @@ __global__ __launch_bounds__(256) void k_active_count(const u64 *__restrict__ co
     if (threadIdx.x == 0) blk_active[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// second pass: positions of the set bits, from the wave masks alone (the codes are not read again)
-__global__ __launch_bounds__(256) void k_active_emit(const u64 *__restrict__ act_mask, u64 n_reps, const u64 *__restrict__ blk_off,
+// second pass: positions of the set bits, from the wave masks alone (the codes are not read again): one thread per
+// mask word = 64 records; blk_off counts per 4 words (the counting pass's blocks)
+__global__ __launch_bounds__(256) void k_active_emit(const u64 *__restrict__ act_mask, u64 n_words, const u64 *__restrict__ blk_off,
                                                      u32 *__restrict__ active)
 {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u64 w0 = (u64)blockIdx.x * 4;
-    const u64 n_words = (n_reps + 63) >> 6;
-    const u64 bal = (w0 + wv < n_words) ? act_mask[w0 + wv] : 0;
-    if (!((bal >> lane) & 1ull)) return;
-    u32 pre = 0;
-    for (int w = 0; w < wv; w++) pre += (u32)__popcll(act_mask[w0 + w]);
-    active[blk_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = (u32)i;
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    u64 bal = act_mask[w];
+    if (!bal) return;
+    u64 at = blk_off[w >> 2];
+    for (u64 v = w & ~3ull; v < w; v++) at += (u32)__popcll(act_mask[v]);
+    while (bal) {
+        const int b = __ffsll((long long)bal) - 1;
+        active[at++] = (u32)(w * 64 + b);
+        bal &= bal - 1;
+    }
 }
 
 // One thread per active record i (k-mer 1).  It is compared with every EARLIER record of its equal-code
@@ -1111,7 +1125,7 @@ void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 
 }
 void launch_kmer_count(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 n_blocks)
 {
-    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, p, bad, block_counts);
+    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, p, bad, block_counts, (u32 *)nullptr);
 }
 void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 n_blocks,
                       u64 *key_hi, u64 *key_lo, u32 *gpos)
@@ -1125,11 +1139,6 @@ void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_p
 void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCounters *ctr)
 {
     if (p.n_contigs) hipLaunchKernelGGL(k_contig_scan, dim3(p.n_contigs), dim3(256), 0, s, p, bad, ctr);
-}
-void launch_kmer_emit_hashed(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 n_blocks,
-                             u64 *rec, u32 *gpos)
-{
-    hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, p, pk, bad, block_off, rec, gpos);
 }
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
                         u32 *head_flag, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr)
@@ -1162,6 +1171,10 @@ void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32
 void launch_nonrep_mark(hipStream_t s, const u32 *head_flag, const u32 *gpos, u64 n, u32 *nonrep)
 {
     if (n) hipLaunchKernelGGL(k_nonrep_mark, grid_for(n), dim3(256), 0, s, head_flag, gpos, n, nonrep);
+}
+void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words)
+{
+    if (n_words) hipLaunchKernelGGL(k_rep_mask_words, grid_for(n_words), dim3(256), 0, s, valid, nonrep, rep, n_words);
 }
 void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep)
 {
@@ -1218,7 +1231,8 @@ void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_a
 }
 void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u64 *blk_off, u32 *active)
 {
-    if (n_reps) hipLaunchKernelGGL(k_active_emit, grid_for(n_reps), dim3(256), 0, s, act_mask, n_reps, blk_off, active);
+    const u64 n_words = (n_reps + 63) >> 6;
+    if (n_reps) hipLaunchKernelGGL(k_active_emit, grid_for(n_words), dim3(256), 0, s, act_mask, n_words, blk_off, active);
 }
 void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
                          u32 *cnt_recs, u32 *cnt_cand)
@@ -1364,19 +1378,19 @@ void launch_count_dest(hipStream_t s, const u64 *dest, u64 n, u32 world, unsigne
 }  // namespace cora
 
 namespace cora {
-void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 block_lo, u32 n_blocks)
+void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 block_lo, u32 n_blocks, u32 *valid)
 {
     if (!n_blocks) return;
     DevParams q = p;
     q.pos_base = (u64)block_lo * 256;
-    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, q, bad, block_counts);
+    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, q, bad, block_counts, valid);
 }
-void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 block_lo,
+void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *valid, const u64 *block_off, u32 block_lo,
                                    u32 n_blocks, u64 *rec, u32 *gpos)
 {
     if (!n_blocks) return;
     DevParams q = p;
     q.pos_base = (u64)block_lo * 256;
-    hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, q, pk, bad, block_off, rec, gpos);
+    hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, q, pk, valid, block_off, rec, gpos);
 }
 }  // namespace cora

@@ -64,8 +64,6 @@ void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u3
                       u32 n_blocks, u64 *key_hi, u64 *key_lo, u32 *gpos);
 void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);
 void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCounters *ctr);
-void launch_kmer_emit_hashed(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
-                             u32 n_blocks, u64 *rec, u32 *gpos);
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
                         u32 *head_flag, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr);
 void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u32 *head_flag,
@@ -77,6 +75,7 @@ void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u3
 void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls,
                        u64 *cls /* rep<<32 | class index */, const u64 *nons_off);
 void launch_nonrep_mark(hipStream_t s, const u32 *head_flag, const u32 *gpos, u64 n, u32 *nonrep);
+void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words);
 void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep /* may alias nonrep */);
 void launch_flag_count(hipStream_t s, const u32 *flag, u64 n, u32 *blk_count /* [ceil(n/256)] */);
 void launch_flag_emit(hipStream_t s, const u32 *flag, u64 n, const u64 *blk_off, u32 *pos);
@@ -125,7 +124,8 @@ void launch_window_counts(hipStream_t s, const u64 *item_key, u64 m, const u32 *
 void launch_dest_by_cuts(hipStream_t s, const u64 *item_key, u64 m, const u32 *cuts, u32 n_cuts, u64 *dest);
 void launch_count_dest(hipStream_t s, const u64 *dest, u64 n, u32 world, unsigned long long *counts);
 // emit hashed records / count windows of a block range [block_lo, block_hi) of 256 positions each
-void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 block_lo, u32 n_blocks);
-void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
+void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 block_lo, u32 n_blocks,
+                             u32 *valid /* window-validity bitmap, written for the blocks of the range */);
+void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *valid, const u64 *block_off,
                                    u32 block_lo, u32 n_blocks, u64 *rec, u32 *gpos);
 }  // namespace cora

@@ -23,14 +23,14 @@ int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf
     DBuf<u32> bc;
     DBuf<u64> boff, scr, tot;
     RCQ(bc.alloc(n_blocks)); RCQ(boff.alloc(n_blocks)); RCQ(scr.alloc(scan_scratch_elems(n_blocks))); RCQ(tot.alloc(1));
-    launch_kmer_count_range(s, dp, job->bad.p, bc.p, block_lo, n_blocks);
+    launch_kmer_count_range(s, dp, job->bad.p, bc.p, block_lo, n_blocks, job->valid.p);
     if (exclusive_scan_u32_to_u64(s, bc.p, boff.p, n_blocks, scr.p, tot.p)) return fail(100, "scan launch failed");
     u64 n = 0;
     HIPQ(hipMemcpyAsync(&n, tot.p, sizeof n, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
     n_out = n;
     RCQ(rec.alloc(n)); RCQ(gp.alloc(n));
-    launch_kmer_emit_hashed_range(s, dp, job->pk.p, job->bad.p, boff.p, block_lo, n_blocks, rec.p, gp.p);
+    launch_kmer_emit_hashed_range(s, dp, job->pk.p, job->valid.p, boff.p, block_lo, n_blocks, rec.p, gp.p);
     HIPQ(hipStreamSynchronize(s));
     return 0;
 }
