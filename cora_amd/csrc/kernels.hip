@@ -256,13 +256,13 @@ __global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64
 // SMALLER than its predecessor's inside an equal-hash run means two different keys collided and are not
 // grouped yet: such positions are listed for k_mixed_fix.
 __global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ rec,
-                                                     const u32 *__restrict__ gpos, u64 n, int hb, u32 *__restrict__ head_flag,
+                                                     const u32 *__restrict__ gpos, u64 n, int hb, u64 *__restrict__ head_mask,
                                                      u32 *__restrict__ mixed_list, u32 mixed_cap, DevCounters *ctr)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    u32 head = 1;
-    if (i > 0 && (rec[i] >> (64 - hb)) == (rec[i - 1] >> (64 - hb))) {
+    u32 head = 0;
+    if (i < n) head = 1;
+    if (i < n && i > 0 && (rec[i] >> (64 - hb)) == (rec[i - 1] >> (64 - hb))) {
         u64 ah, al, bh, bl;
         canonical_at(p, pk, gpos[i - 1], ah, al);
         canonical_at(p, pk, gpos[i], bh, bl);
@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__r
             if (at < mixed_cap) mixed_list[at] = (u32)i;
         }
     }
-    head_flag[i] = head;
+    const u64 bal = __ballot(head != 0);                    // bit l of word i/64 = record 64*(i/64)+l opens a class
+    if ((threadIdx.x & 63) == 0) head_mask[i >> 6] = bal;
 }
 
 // One thread per listed position: the lowest listed position of an equal-hash run sorts that run by
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__r
 // fallback flag: the caller then redoes the stage with the full-key sort.
 __global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__restrict__ pk, u64 *__restrict__ rec,
                                                   u32 *__restrict__ gpos, u64 n, int hb, const u32 *__restrict__ mixed_list,
-                                                  u32 n_mixed, u32 *__restrict__ head_flag, DevCounters *ctr)
+                                                  u32 n_mixed, u64 *head_mask, DevCounters *ctr)
 {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t >= n_mixed) return;
@@ -303,7 +304,9 @@ __global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__rest
     }
     for (int k = 0; k < L; k++) {                         // the run in key order, and its class heads
         rec[s + k] = r_[k]; gpos[s + k] = g_[k];
-        head_flag[s + k] = (k == 0 || kh[k] != kh[k - 1] || kl[k] != kl[k - 1]) ? 1u : 0u;
+        const u64 bit = 1ull << ((s + k) & 63);           // other runs may share the word
+        if (k == 0 || kh[k] != kh[k - 1] || kl[k] != kl[k - 1]) atomicOr((unsigned long long *)&head_mask[(s + k) >> 6], bit);
+        else atomicAnd((unsigned long long *)&head_mask[(s + k) >> 6], ~bit);
     }
 }
 
@@ -311,11 +314,13 @@ __global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__rest
 // flag byte rebuilt from the genome.
 __global__ __launch_bounds__(256) void k_heads_from_keys(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ hi,
                                                          const u64 *__restrict__ lo, const u32 *__restrict__ gpos, u64 n,
-                                                         u32 *__restrict__ head_flag, u64 *__restrict__ rec)
+                                                         u64 *__restrict__ head_mask, u64 *__restrict__ rec)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool head = i < n && ((i == 0) || hi[i - 1] != hi[i] || lo[i - 1] != lo[i]);
+    const u64 bal = __ballot(head);
+    if ((threadIdx.x & 63) == 0) head_mask[i >> 6] = bal;
     if (i >= n) return;
-    head_flag[i] = ((i == 0) || hi[i - 1] != hi[i] || lo[i - 1] != lo[i]) ? 1u : 0u;
     u64 fh, fl, rh, rl;
     load_window(p, pk, gpos[i], fh, fl);
     rc_window(p.K, fh, fl, rh, rl);
@@ -424,11 +429,11 @@ __global__ __launch_bounds__(256) void k_min_u64(const unsigned long long *__res
 // later member of a class.  Later members are few (the repeated K-mers), so they are what gets marked, by
 // atomics, in a zeroed bitmap; k_rep_mask then turns "valid and not marked" into the representative bitmap.
 // (Marking the representatives themselves cost one scattered atomic per distinct K-mer: 2.4 ms per 64 Mbp.)
-__global__ __launch_bounds__(256) void k_nonrep_mark(const u32 *__restrict__ head_flag, const u32 *__restrict__ gpos, u64 n,
+__global__ __launch_bounds__(256) void k_nonrep_mark(const u64 *__restrict__ head_mask, const u32 *__restrict__ gpos, u64 n,
                                                      u32 *__restrict__ nonrep)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || head_flag[i]) return;
+    if (i >= n || ((head_mask[i >> 6] >> (i & 63)) & 1ull)) return;
     const u32 g = gpos[i];
     atomicOr(&nonrep[g >> 5], 1u << (31 - (g & 31)));
 }
@@ -479,31 +484,32 @@ __global__ __launch_bounds__(256) void k_class_emit(const u64 *__restrict__ rec,
     }
 }
 
-// ------------------------------------------------------------------ flags -> positions of the set flags
-// (two light passes and a scan over the per-block counts instead of a full-length prefix sum)
-__global__ __launch_bounds__(256) void k_flag_count(const u32 *__restrict__ flag, u64 n, u32 *__restrict__ blk_count)
+// ------------------------------------------------------------------ record mask -> positions of the set bits
+// mask word w covers records 64w .. 64w+63 (bit l = record 64w+l).  One thread per word; blocks of 256 words.
+__global__ __launch_bounds__(256) void k_mask_count(const u64 *__restrict__ mask, u64 n_words, u32 *__restrict__ blk_count)
 {
     __shared__ u32 ws[4];
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    const u64 bal = __ballot(i < n && flag[i] != 0);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (u32)__popcll(bal);
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 c = (w < n_words) ? (u32)__popcll(mask[w]) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) blk_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-__global__ __launch_bounds__(256) void k_flag_emit(const u32 *__restrict__ flag, u64 n, const u64 *__restrict__ blk_off, u32 *__restrict__ pos)
+__global__ __launch_bounds__(256) void k_mask_emit(const u64 *__restrict__ mask, u64 n_words, const u64 *__restrict__ blk_off,
+                                                   u32 *__restrict__ pos)
 {
-    __shared__ u32 ws[4];
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool set = i < n && flag[i] != 0;
-    const u64 bal = __ballot(set);
-    if (lane == 0) ws[wv] = (u32)__popcll(bal);
-    __syncthreads();
-    if (!set) return;
-    u32 pre = 0;
-    for (int w = 0; w < wv; w++) pre += ws[w];
-    pos[blk_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = (u32)i;
+    __shared__ u32 l4[4];
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 bal = (w < n_words) ? mask[w] : 0;
+    u64 at = blk_off[blockIdx.x] + block_excl_scan_u32((u32)__popcll(bal), l4, nullptr);
+    while (bal) {
+        const int b = __ffsll((long long)bal) - 1;
+        pos[at++] = (u32)(w * 64 + b);
+        bal &= bal - 1;
+    }
 }
 
 // ------------------------------------------------------------------ bitmap -> sorted position list
@@ -1141,19 +1147,19 @@ void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCo
     if (p.n_contigs) hipLaunchKernelGGL(k_contig_scan, dim3(p.n_contigs), dim3(256), 0, s, p, bad, ctr);
 }
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
-                        u32 *head_flag, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr)
+                        u64 *head_mask, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr)
 {
-    if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_flag, mixed_list, mixed_cap, ctr);
+    if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_mask, mixed_list, mixed_cap, ctr);
 }
-void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u32 *head_flag, const u32 *mixed_list,
+void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u64 *head_mask, const u32 *mixed_list,
                       u32 n_mixed, DevCounters *ctr)
 {
-    if (n_mixed) hipLaunchKernelGGL(k_mixed_fix, dim3((n_mixed + 63) / 64), dim3(64), 0, s, p, pk, rec, gpos, n, hb, mixed_list, n_mixed, head_flag, ctr);
+    if (n_mixed) hipLaunchKernelGGL(k_mixed_fix, dim3((n_mixed + 63) / 64), dim3(64), 0, s, p, pk, rec, gpos, n, hb, mixed_list, n_mixed, head_mask, ctr);
 }
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
-                            u32 *head_flag, u64 *rec)
+                            u64 *head_mask, u64 *rec)
 {
-    if (n) hipLaunchKernelGGL(k_heads_from_keys, grid_for(n), dim3(256), 0, s, p, pk, hi, lo, gpos, n, head_flag, rec);
+    if (n) hipLaunchKernelGGL(k_heads_from_keys, grid_for(n), dim3(256), 0, s, p, pk, hi, lo, gpos, n, head_mask, rec);
 }
 void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
                         unsigned long long *blk_min, DevCounters *ctr)
@@ -1168,9 +1174,9 @@ void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32
 {
     if (n_cls) hipLaunchKernelGGL(k_class_emit, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, n_cls, cls, nons_off);
 }
-void launch_nonrep_mark(hipStream_t s, const u32 *head_flag, const u32 *gpos, u64 n, u32 *nonrep)
+void launch_nonrep_mark(hipStream_t s, const u64 *head_mask, const u32 *gpos, u64 n, u32 *nonrep)
 {
-    if (n) hipLaunchKernelGGL(k_nonrep_mark, grid_for(n), dim3(256), 0, s, head_flag, gpos, n, nonrep);
+    if (n) hipLaunchKernelGGL(k_nonrep_mark, grid_for(n), dim3(256), 0, s, head_mask, gpos, n, nonrep);
 }
 void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words)
 {
@@ -1180,13 +1186,13 @@ void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u3
 {
     hipLaunchKernelGGL(k_rep_mask, grid_for(p.G), dim3(256), 0, s, p, bad, nonrep, rep);
 }
-void launch_flag_count(hipStream_t s, const u32 *flag, u64 n, u32 *blk_count)
+void launch_mask_count(hipStream_t s, const u64 *mask, u64 n_words, u32 *blk_count)
 {
-    if (n) hipLaunchKernelGGL(k_flag_count, grid_for(n), dim3(256), 0, s, flag, n, blk_count);
+    if (n_words) hipLaunchKernelGGL(k_mask_count, grid_for(n_words), dim3(256), 0, s, mask, n_words, blk_count);
 }
-void launch_flag_emit(hipStream_t s, const u32 *flag, u64 n, const u64 *blk_off, u32 *pos)
+void launch_mask_emit(hipStream_t s, const u64 *mask, u64 n_words, const u64 *blk_off, u32 *pos)
 {
-    if (n) hipLaunchKernelGGL(k_flag_emit, grid_for(n), dim3(256), 0, s, flag, n, blk_off, pos);
+    if (n_words) hipLaunchKernelGGL(k_mask_emit, grid_for(n_words), dim3(256), 0, s, mask, n_words, blk_off, pos);
 }
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks)
 {

@@ -65,20 +65,20 @@ void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u3
 void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);
 void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCounters *ctr);
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
-                        u32 *head_flag, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr);
-void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u32 *head_flag,
+                        u64 *head_mask /* [ceil(n/256)*4], bit l of word w = record 64w+l */, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr);
+void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u64 *head_mask,
                       const u32 *mixed_list, u32 n_mixed, DevCounters *ctr);
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
-                            u64 n, u32 *head_flag, u64 *rec);
+                            u64 n, u64 *head_mask, u64 *rec);
 void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
                         unsigned long long *blk_min, DevCounters *ctr);
 void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls,
                        u64 *cls /* rep<<32 | class index */, const u64 *nons_off);
-void launch_nonrep_mark(hipStream_t s, const u32 *head_flag, const u32 *gpos, u64 n, u32 *nonrep);
+void launch_nonrep_mark(hipStream_t s, const u64 *head_mask, const u32 *gpos, u64 n, u32 *nonrep);
 void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words);
 void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep /* may alias nonrep */);
-void launch_flag_count(hipStream_t s, const u32 *flag, u64 n, u32 *blk_count /* [ceil(n/256)] */);
-void launch_flag_emit(hipStream_t s, const u32 *flag, u64 n, const u64 *blk_off, u32 *pos);
+void launch_mask_count(hipStream_t s, const u64 *mask, u64 n_words, u32 *blk_count /* [ceil(n_words/256)] */);
+void launch_mask_emit(hipStream_t s, const u64 *mask, u64 n_words, const u64 *blk_off, u32 *pos);
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks);
 void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out, u32 base);
 void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,

@@ -45,9 +45,10 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     cora_hip_stats &st = job->stats;
     const u64 N = x.N;
     if (N >= (1ull << 32) - 1) return fail(19, "too many K-mers for 32-bit indices");
-    DBuf<u32> head_flag, mixed_list;
+    DBuf<u64> head_flag;                        // one bit per record: opens a class
+    DBuf<u32> mixed_list;
     const u32 mixed_cap = 4096;
-    RCQ(x.trec.alloc(N)); RCQ(x.tgp.alloc(N)); RCQ(head_flag.alloc(N)); RCQ(mixed_list.alloc(mixed_cap));
+    RCQ(x.trec.alloc(N)); RCQ(x.tgp.alloc(N)); RCQ(head_flag.alloc(((N + 255) / 256) * 4)); RCQ(mixed_list.alloc(mixed_cap));
     // Equal canonical keys have equal hashes: sort 12-byte (hash, position) records on the top hb hash bits
     // (6-7 passes) instead of 20-byte full keys on 2K bits (13 passes); collisions are found and repaired below.
     const int hb = job->hash_bits ? job->hash_bits : (N <= (1ull << 27) ? 48 : 56);
@@ -87,16 +88,16 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     launch_nonrep_mark(s, head_flag.p, x.gp_s, N, x.nonrep.p);
     // class starts = positions of the head flags
     {
-        const u64 nb = (N + 255) / 256;
+        const u64 n_words = (N + 63) / 64, nb = (n_words + 255) / 256;
         DBuf<u32> bcnt;
         DBuf<u64> boff, scr0, tot0;
         RCQ(bcnt.alloc(nb)); RCQ(boff.alloc(nb)); RCQ(scr0.alloc(scan_scratch_elems(nb))); RCQ(tot0.alloc(1));
-        launch_flag_count(s, head_flag.p, N, bcnt.p);
+        launch_mask_count(s, head_flag.p, n_words, bcnt.p);
         if (exclusive_scan_u32_to_u64(s, bcnt.p, boff.p, nb, scr0.p, tot0.p)) return fail(100, "scan launch failed");
         HIPQ(hipMemcpyAsync(&x.NR, tot0.p, sizeof x.NR, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
         RCQ(x.class_start.alloc(x.NR + 1));
-        launch_flag_emit(s, head_flag.p, N, boff.p, x.class_start.p);
+        launch_mask_emit(s, head_flag.p, n_words, boff.p, x.class_start.p);
         const u32 n32 = (u32)N;
         HIPQ(hipMemcpyAsync(x.class_start.p + x.NR, &n32, sizeof(u32), hipMemcpyHostToDevice, s));
         HIPQ(hipStreamSynchronize(s));          // n32 lives on this frame
