@@ -377,7 +377,8 @@ __device__ __forceinline__ bool key_is_palindrome(int K, u64 hi, u64 lo)
 // partials instead of global counters: same-address atomics cost about 12 ns each chip-wide.
 __global__ __launch_bounds__(256) void k_class_count(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
                                                      const u32 *__restrict__ class_start, u32 n_cls,
-                                                     u32 *__restrict__ blk_nons, unsigned long long *__restrict__ blk_min)
+                                                     u32 *__restrict__ blk_nons, unsigned long long *__restrict__ blk_min,
+                                                     u64 *__restrict__ nons_mask)
 {
     __shared__ u32 s_nons[4];
     __shared__ unsigned long long s_min[4];
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void k_class_count(const u64 *__restrict__ rec
     }
     const u64 bn = __ballot(nons);
     const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; }
+    if ((threadIdx.x & 63) == 0) { s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; nons_mask[c >> 6] = bn; }   // kept for k_class_emit
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_nons[blockIdx.x] = s_nons[0] + s_nons[1] + s_nons[2] + s_nons[3];
@@ -459,29 +460,19 @@ __global__ __launch_bounds__(256) void k_rep_mask(DevParams p, const u32 *__rest
 }
 
 // Lists the classes with >= 2 entries as rep<<32 | class index, at offsets from the scan of blk_nons.
-__global__ __launch_bounds__(256) void k_class_emit(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
-                                                    const u32 *__restrict__ class_start, u32 n_cls,
-                                                    u64 *__restrict__ cls, const u64 *__restrict__ nons_off)
+__global__ __launch_bounds__(256) void k_class_emit(const u32 *__restrict__ gpos, const u32 *__restrict__ class_start, u32 n_cls,
+                                                    const u64 *__restrict__ nons_mask, u64 *__restrict__ cls,
+                                                    const u64 *__restrict__ nons_off)
 {
-    __shared__ u32 s_nons[4];
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    bool nons = false;
-    u32 g = 0;
-    if (c < n_cls) {
-        const u32 st = class_start[c], m = class_start[c + 1] - st;
-        g = gpos[st];
-        nons = !(m == 1 && !((u32)rec[st] & 2u));
-    }
-    const u64 bn = __ballot(nons);
-    if (lane == 0) s_nons[wv] = (u32)__popcll(bn);
-    __syncthreads();
-    if (nons) {
-        u32 pre = 0;
-        for (int w = 0; w < wv; w++) pre += s_nons[w];
-        const u64 at = nons_off[blockIdx.x] + pre + (u32)__popcll(bn & ((1ull << lane) - 1ull));
-        cls[at] = ((u64)g << 32) | (u64)c;
-    }
+    const u64 w0 = (u64)blockIdx.x * 4;
+    const u64 bn = nons_mask[w0 + wv];                        // written for every wave of k_class_count's grid (same geometry)
+    if (c >= n_cls || !((bn >> lane) & 1ull)) return;
+    u32 pre = 0;
+    for (int w = 0; w < wv; w++) pre += (u32)__popcll(nons_mask[w0 + w]);
+    const u64 at = nons_off[blockIdx.x] + pre + (u32)__popcll(bn & ((1ull << lane) - 1ull));
+    cls[at] = ((u64)gpos[class_start[c]] << 32) | (u64)c;
 }
 
 // ------------------------------------------------------------------ record mask -> positions of the set bits
@@ -1162,17 +1153,17 @@ void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, co
     if (n) hipLaunchKernelGGL(k_heads_from_keys, grid_for(n), dim3(256), 0, s, p, pk, hi, lo, gpos, n, head_mask, rec);
 }
 void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
-                        unsigned long long *blk_min, DevCounters *ctr)
+                        unsigned long long *blk_min, u64 *nons_mask, DevCounters *ctr)
 {
     if (!n_cls) return;
     const dim3 g = grid_for(n_cls);
-    hipLaunchKernelGGL(k_class_count, g, dim3(256), 0, s, rec, gpos, class_start, n_cls, blk_nons, blk_min);
+    hipLaunchKernelGGL(k_class_count, g, dim3(256), 0, s, rec, gpos, class_start, n_cls, blk_nons, blk_min, nons_mask);
     hipLaunchKernelGGL(k_min_u64, dim3(g.x < 64 ? g.x : 64), dim3(256), 0, s, blk_min, (u64)g.x, &ctr->first_singleton_key);
 }
-void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u64 *cls,
+void launch_class_emit(hipStream_t s, const u32 *gpos, const u32 *class_start, u32 n_cls, const u64 *nons_mask, u64 *cls,
                        const u64 *nons_off)
 {
-    if (n_cls) hipLaunchKernelGGL(k_class_emit, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, n_cls, cls, nons_off);
+    if (n_cls) hipLaunchKernelGGL(k_class_emit, grid_for(n_cls), dim3(256), 0, s, gpos, class_start, n_cls, nons_mask, cls, nons_off);
 }
 void launch_nonrep_mark(hipStream_t s, const u64 *head_mask, const u32 *gpos, u64 n, u32 *nonrep)
 {

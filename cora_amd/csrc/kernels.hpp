@@ -71,8 +71,8 @@ void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
                             u64 n, u64 *head_mask, u64 *rec);
 void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
-                        unsigned long long *blk_min, DevCounters *ctr);
-void launch_class_emit(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls,
+                        unsigned long long *blk_min, u64 *nons_mask /* [ceil(n_cls/256)*4] */, DevCounters *ctr);
+void launch_class_emit(hipStream_t s, const u32 *gpos, const u32 *class_start, u32 n_cls, const u64 *nons_mask,
                        u64 *cls /* rep<<32 | class index */, const u64 *nons_off);
 void launch_nonrep_mark(hipStream_t s, const u64 *head_mask, const u32 *gpos, u64 n, u32 *nonrep);
 void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words);

@@ -106,15 +106,15 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
 
     const u32 kb = (u32)((x.NR + 255) / 256);
     DBuf<u32> blk_nons;
-    DBuf<u64> blk_min, nons_off, scr2, tots;
-    RCQ(blk_nons.alloc(kb)); RCQ(blk_min.alloc(kb)); RCQ(nons_off.alloc(kb));
+    DBuf<u64> blk_min, nons_off, scr2, tots, nons_mask;
+    RCQ(blk_nons.alloc(kb)); RCQ(blk_min.alloc(kb)); RCQ(nons_off.alloc(kb)); RCQ(nons_mask.alloc((u64)kb * 4));
     RCQ(scr2.alloc(scan_scratch_elems(kb))); RCQ(tots.alloc(1));
-    launch_class_count(s, x.rec_s, x.gp_s, x.class_start.p, (u32)x.NR, blk_nons.p, (unsigned long long *)blk_min.p, job->ctr.p);
+    launch_class_count(s, x.rec_s, x.gp_s, x.class_start.p, (u32)x.NR, blk_nons.p, (unsigned long long *)blk_min.p, nons_mask.p, job->ctr.p);
     if (exclusive_scan_u32_to_u64(s, blk_nons.p, nons_off.p, kb, scr2.p, tots.p)) return fail(100, "scan launch failed");
     HIPQ(hipMemcpyAsync(&x.NNS, tots.p, sizeof x.NNS, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
     RCQ(x.cls.alloc(x.NNS));
-    launch_class_emit(s, x.rec_s, x.gp_s, x.class_start.p, (u32)x.NR, x.cls.p, nons_off.p);
+    launch_class_emit(s, x.gp_s, x.class_start.p, (u32)x.NR, nons_mask.p, x.cls.p, nons_off.p);
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
     return 0;
