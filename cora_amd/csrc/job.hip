@@ -43,6 +43,7 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
     memcpy(hg.sig2, params->sig2, 16);
     memcpy(hg.sig4, params->sig4, 256);
     make_seed_template(hg.K, hg.d, hg.tmpl, &hg.seed_q);
+    if (const char *e = getenv("CORA_SKETCH")) j->sketch_mode = atoi(e) != 0;
     if (const char *e = getenv("CORA_HASH_BITS")) { int v = atoi(e); if (v >= 8 && v <= 56) j->hash_bits = v & ~7; }
     if (const char *e = getenv("CORA_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) j->host_threads = v; }
     if (hipStreamCreate(&j->stream) != hipSuccess) { delete j; return fail(100, "hipStreamCreate failed"); }
@@ -182,18 +183,22 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     {
         // every seed's codes in one pass over the representatives, each with its first-digit tile histogram
         DBuf<u64> codes[CORA_HIP_MAX_SEEDS];
-        DBuf<u32> hists[CORA_HIP_MAX_SEEDS];
+        DBuf<u32> hists[CORA_HIP_MAX_SEEDS], sketches[CORA_HIP_MAX_SEEDS];
         u64 *cp[4] = {nullptr, nullptr, nullptr, nullptr};
-        u32 *hp[4] = {nullptr, nullptr, nullptr, nullptr};
+        u32 *hp[4] = {nullptr, nullptr, nullptr, nullptr}, *kp[4] = {nullptr, nullptr, nullptr, nullptr};
+        // Chance collisions of 32-bit seed codes grow with NR^2 / 2^32: from a few hundred million representatives on they
+        // dominate verification, and a 4-byte sketch carried through the sort pays for itself (k_verify's pre-filter).
+        const bool use_sketch = job->sketch_mode >= 0 ? job->sketch_mode != 0 : NR > (1ull << 28);
         const u64 tiles = (NR + RS_TILE_MIN - 1) / RS_TILE_MIN;
         for (int q = 0; q < dp.nseeds; q++) {
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
             cp[q] = codes[q].p; hp[q] = hists[q].p;
+            if (use_sketch) { RCQ(sketches[q].alloc(NR)); kp[q] = sketches[q].p; }
         }
-        launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp);
+        launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, kp);
         for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
-            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p));
-            codes[seed - 1].release(); hists[seed - 1].release();
+            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, kp[seed - 1]));
+            codes[seed - 1].release(); hists[seed - 1].release(); sketches[seed - 1].release();
         }
         st.hom_pairs = ps.n;
     }

@@ -150,6 +150,7 @@ struct cora_hip_job {
     HBuf<int16_t> h_blen;
     int host_threads = 8;
     struct ShardState *shard = nullptr;   // multi-GPU stage state (shard.hip)
+    int sketch_mode = -1;         // -1 = by size (on above 2^28 representatives); CORA_SKETCH=0/1 overrides
     int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
     ByteBuf exact_bytes, inexact_bytes;
     cora_hip_stats stats;
@@ -219,6 +220,7 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x);
 int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p);
 int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &host_ms);
 int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBuf<u32> &reps, u64 &n_out);
-int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist = nullptr);
+int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist = nullptr,
+                   u32 *sketch = nullptr /* [n] per-record sketches for k_verify's pre-filter; sorted along */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);

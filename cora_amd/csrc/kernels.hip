@@ -633,7 +633,8 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ reps, u64 n_reps,
                                                         u64 *__restrict__ out0, u64 *__restrict__ out1, u64 *__restrict__ out2,
                                                         u64 *__restrict__ out3, u32 *__restrict__ hist0, u32 *__restrict__ hist1,
-                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3)
+                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3, u32 *__restrict__ sk0,
+                                                        u32 *__restrict__ sk1, u32 *__restrict__ sk2, u32 *__restrict__ sk3)
 {
     __shared__ u32 h[NS][256];
     const int tid = threadIdx.x;
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
     for (int s = 0; s < NS; s++) h[s][tid] = 0;
     __syncthreads();
     u64 *const outs[4] = {out0, out1, out2, out3};
+    u32 *const sks[4] = {sk0, sk1, sk2, sk3};
     const u64 base = (u64)blockIdx.x * 4096;
 #pragma unroll 4
     for (int k = 0; k < 16; k++) {
@@ -649,12 +651,18 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
         const u32 g = reps[r];
         u64 hi, lo;
         load_window(p, pk, g, hi, lo);
+        u32 fwc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) fwc[s] = seed_code(p, hi, lo, s + 1);
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            const u32 fw = seed_code(p, hi, lo, s + 1), rc = rc_code(fw);
+            const u32 fw = fwc[s], rc = rc_code(fw);
             const u32 c = fw <= rc ? fw : rc;
             outs[s][r] = ((u64)c << 32) | g;
             atomicAdd(&h[s][c & 255u], 1u);
+            // sketch of the record: the NEXT seed's code in the orientation that made this code canonical.  Two K-mers
+            // within d mismatches whose seed s agrees differ in at most d bases of it (k_verify's pre-filter).
+            if (sks[s]) { const u32 o = fwc[(s + 1) % NS]; sks[s][r] = fw <= rc ? o : rc_code(o); }
         }
     }
     __syncthreads();
@@ -744,7 +752,8 @@ __global__ __launch_bounds__(256) void k_active_emit(const u64 *__restrict__ act
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ codes,
                                                 const u32 *__restrict__ active, u32 n_active, int seed, u32 *__restrict__ cnt_recs,
-                                                u32 *__restrict__ cnt_cand, const u64 *__restrict__ rec_off, PairRec *__restrict__ pairs)
+                                                u32 *__restrict__ cnt_cand, const u64 *__restrict__ rec_off, PairRec *__restrict__ pairs,
+                                                const u32 *__restrict__ sketch)
 {
     constexpr u32 INV = 0xFFFFFFFFu;
     const u32 t = blockIdx.x * 256 + threadIdx.x;
@@ -758,6 +767,10 @@ __global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restri
     u64 ih, il;
     load_window(p, pk, gi, ih, il);
     const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
+    // Pre-filter (large references: random code collisions grow with N^2 / 2^32): the sketches of two records that
+    // can be reported differ in at most d bases, so most chance partners are dismissed without touching the genome.
+    const bool filter = sketch != nullptr && !pal;
+    const u32 ski = filter ? sketch[i] : 0u;
     if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
         u64 rh, rl;
         rc_window(p.K, ih, il, rh, rl);
@@ -772,6 +785,10 @@ __global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restri
         const u64 cj = codes[j];
         if ((u32)(cj >> 32) != code) break;
         const u32 gj = (u32)cj;
+        if (filter) {
+            const u32 x = ski ^ sketch[j];
+            if (__popc((x | (x >> 1)) & 0x55555555u) > p.d) { ncand++; continue; }      // still a comparison the reference makes
+        }
         u64 jh, jl, rh, rl;
         load_window(p, pk, gj, jh, jl);
         rc_window(p.K, jh, jl, rh, rl);
@@ -1212,14 +1229,15 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
 {
     if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
 }
-void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4])
+void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
+                           u32 *const sk[4])
 {
     if (!n_reps) return;
     const dim3 g((unsigned)((n_reps + 4095) / 4096));
     switch (p.nseeds) {
-    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3]); break;
-    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3]); break;
-    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3]); break;
+    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk[0], sk[1], sk[2], sk[3]); break;
+    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk[0], sk[1], sk[2], sk[3]); break;
+    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk[0], sk[1], sk[2], sk[3]); break;
     }
 }
 void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active, u64 *act_mask)
@@ -1232,16 +1250,16 @@ void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u6
     if (n_reps) hipLaunchKernelGGL(k_active_emit, grid_for(n_words), dim3(256), 0, s, act_mask, n_words, blk_off, active);
 }
 void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
-                         u32 *cnt_recs, u32 *cnt_cand)
+                         u32 *cnt_recs, u32 *cnt_cand, const u32 *sketch)
 {
     if (n_active) hipLaunchKernelGGL((k_verify<false>), grid_for(n_active), dim3(256), 0, s, p, pk, codes, active, n_active, seed, cnt_recs,
-                                     cnt_cand, (const u64 *)nullptr, (PairRec *)nullptr);
+                                     cnt_cand, (const u64 *)nullptr, (PairRec *)nullptr, sketch);
 }
 void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
-                         const u64 *rec_off, PairRec *pairs)
+                         const u64 *rec_off, PairRec *pairs, const u32 *sketch)
 {
     if (n_active) hipLaunchKernelGGL((k_verify<true>), grid_for(n_active), dim3(256), 0, s, p, pk, codes, active, n_active, seed,
-                                     (u32 *)nullptr, (u32 *)nullptr, rec_off, pairs);
+                                     (u32 *)nullptr, (u32 *)nullptr, rec_off, pairs, sketch);
 }
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta)
 {

@@ -89,13 +89,14 @@ void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls
                         const u32 *ent, const u8 *ent_dir, u8 *merge_prev);
 void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out);
 // every seed's (code, position) records at once + the first-digit tile histogram of each (tiles of 4096 records)
-void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4]);
+void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
+                           u32 *const sketch[4] /* entries may be null */);
 void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active, u64 *act_mask /* [ceil(n/256)*4] */);
 void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u64 *blk_off, u32 *active);
 void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,
-                         int seed, u32 *cnt_recs, u32 *cnt_cand);
+                         int seed, u32 *cnt_recs, u32 *cnt_cand, const u32 *sketch /* sorted with the codes, or null */);
 void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,
-                         int seed, const u64 *rec_off, PairRec *pairs);
+                         int seed, const u64 *rec_off, PairRec *pairs, const u32 *sketch);
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta);
 void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr);
 void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start);

@@ -218,7 +218,7 @@ int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBu
 
 // One seed: sort the (code, position) records, compact the run members, verify, append the pair records
 // (HTS:2671-2800, 2138-2265).  codes holds n records in which equal codes appear in increasing position.
-int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist)
+int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u32 *sketch)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
@@ -229,8 +229,10 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     DBuf<u64> act_mask;
     RCQ(codes_tmp.alloc(n)); RCQ(blk_active.alloc(vb)); RCQ(blk_off.alloc(vb)); RCQ(act_mask.alloc((u64)vb * 4));
     RCQ(scr.alloc(scan_scratch_elems(vb))); RCQ(tots.alloc(2));
+    DBuf<u32> sketch_tmp;
     SortArrays ck, ct;
     ck.a = codes.p; ct.a = codes_tmp.p;
+    if (sketch) { RCQ(sketch_tmp.alloc(n)); ck.c = sketch; ct.c = sketch_tmp.p; }     // the sketches travel with their records
     if (radix_sort(s, ck, ct, n, 32, 64, job->sort_scratch, &job->sort_timing, first_hist)) return fail(100, "radix sort failed");
     launch_active_count(s, ck.a, n, blk_active.p, act_mask.p);
     if (exclusive_scan_u32_to_u64(s, blk_active.p, blk_off.p, vb, scr.p, tots.p)) return fail(100, "scan launch failed");
@@ -244,7 +246,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     RCQ(active.alloc(n_active)); RCQ(cnt_recs.alloc(n_active)); RCQ(cnt_cand.alloc(n_active));
     RCQ(rec_off.alloc(n_active)); RCQ(cand_off.alloc(n_active)); RCQ(scr_a.alloc(scan_scratch_elems(n_active)));
     launch_active_emit(s, act_mask.p, n, blk_off.p, active.p);
-    launch_verify_count(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, cnt_recs.p, cnt_cand.p);
+    launch_verify_count(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, cnt_recs.p, cnt_cand.p, ck.c);
     if (exclusive_scan_u32_to_u64(s, cnt_recs.p, rec_off.p, n_active, scr_a.p, tots.p)) return fail(100, "scan launch failed");
     if (exclusive_scan_u32_to_u64(s, cnt_cand.p, cand_off.p, n_active, scr_a.p, tots.p + 1)) return fail(100, "scan launch failed");
     u64 totals[2] = {0, 0};
@@ -260,7 +262,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         std::swap(ps.pairs.p, bigger.p); std::swap(ps.pairs.n, bigger.n); std::swap(ps.pairs.pool, bigger.pool);
         ps.cap = want;
     }
-    if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, rec_off.p, ps.pairs.p + ps.n);
+    if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, rec_off.p, ps.pairs.p + ps.n, ck.c);
     ps.n += totals[0];
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());

@@ -178,6 +178,24 @@ def test_hash_collisions_are_repaired(name, bits, expect, monkeypatch):
         assert st["hash_mixed_runs"] > 0
 
 
+# ------------------------------------------------------------------ sketch pre-filter of the verification (large references)
+@pytest.mark.parametrize("name", ["syn_k50_d2", "syn_k50_d1", "syn_k64_d3", "syn_k33_d2", "lowcx_k36_d1", "lowcx_k64_d3", "pal_k50_d2_p4t5",
+                                  "q_k50_d2_p10", "fam_k48_d3", "multi_k50_d2_L", "ecoli_like_k50_d2"])
+def test_sketch_prefilter_changes_nothing(name, monkeypatch):
+    """Above 2**28 representatives every seed record carries a 4-byte sketch through its sort and k_verify dismisses
+    partners whose sketches differ in more than d bases.  CORA_SKETCH=1 forces that path on the small fixtures: same
+    bytes, same number of comparisons counted."""
+    c, want = helpers.golden_case(name)
+    args = (helpers.input_path(c["input"]), c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
+    monkeypatch.setenv("CORA_SKETCH", "0")
+    e0, en0, i0, inn0, st0 = hip.build_tables(*args)
+    monkeypatch.setenv("CORA_SKETCH", "1")
+    e, en, i, inn, st = hip.build_tables(*args)
+    assert e == helpers.read(os.path.join(want, "Exact")) and i == helpers.read(os.path.join(want, "Inexact"))
+    assert (e0, i0) == (e, i)
+    assert st["candidate_pairs"] == st0["candidate_pairs"] and st["hom_pairs"] == st0["hom_pairs"]
+
+
 # ------------------------------------------------------------------ the benchmark workload at full size
 @pytest.mark.parametrize("name", ["chr20_like_k50_d2", "chr20_like_k50_d3"])
 def test_full_size_workload_matches_reference_hash(name):
