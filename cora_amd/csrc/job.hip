@@ -188,7 +188,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         u32 *hp[4] = {nullptr, nullptr, nullptr, nullptr}, *kp[4] = {nullptr, nullptr, nullptr, nullptr};
         // Chance collisions of 32-bit seed codes grow with NR^2 / 2^32: from a few hundred million representatives on they
         // dominate verification, and a 4-byte sketch carried through the sort pays for itself (k_verify's pre-filter).
-        const bool use_sketch = job->sketch_mode >= 0 ? job->sketch_mode != 0 : NR > (1ull << 28);
+        const bool use_sketch = job->sketch_mode >= 0 ? job->sketch_mode != 0 : NR > (1ull << 30);
         const u64 tiles = (NR + RS_TILE_MIN - 1) / RS_TILE_MIN;
         for (int q = 0; q < dp.nseeds; q++) {
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));

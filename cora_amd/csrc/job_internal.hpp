@@ -150,7 +150,7 @@ struct cora_hip_job {
     HBuf<int16_t> h_blen;
     int host_threads = 8;
     struct ShardState *shard = nullptr;   // multi-GPU stage state (shard.hip)
-    int sketch_mode = -1;         // -1 = by size (on above 2^28 representatives); CORA_SKETCH=0/1 overrides
+    int sketch_mode = -1;         // -1 = by size (on above 2^30 representatives); CORA_SKETCH=0/1 overrides
     int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
     ByteBuf exact_bytes, inexact_bytes;
     cora_hip_stats stats;

@@ -764,14 +764,16 @@ __global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restri
     const u64 ci = codes[i];
     const u32 code = (u32)(ci >> 32), gi = (u32)ci;
     const bool pal = rc_code(code) == code;
-    u64 ih, il;
-    load_window(p, pk, gi, ih, il);
+    u64 ih = 0, il = 0;
+    bool have_i = false;                                    // k-mer 1 is fetched when the first partner needs it
     const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
     // Pre-filter (large references: random code collisions grow with N^2 / 2^32): the sketches of two records that
     // can be reported differ in at most d bases, so most chance partners are dismissed without touching the genome.
     const bool filter = sketch != nullptr && !pal;
     const u32 ski = filter ? sketch[i] : 0u;
     if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
+        load_window(p, pk, gi, ih, il);
+        have_i = true;
         u64 rh, rl;
         rc_window(p.K, ih, il, rh, rl);
         const u32 mr = judge(p, mism_of(ih, il, rh, rl), seed, 1);
@@ -789,6 +791,7 @@ __global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restri
             const u32 x = ski ^ sketch[j];
             if (__popc((x | (x >> 1)) & 0x55555555u) > p.d) { ncand++; continue; }      // still a comparison the reference makes
         }
+        if (!have_i) { load_window(p, pk, gi, ih, il); have_i = true; }
         u64 jh, jl, rh, rl;
         load_window(p, pk, gj, jh, jl);
         rc_window(p.K, jh, jl, rh, rl);

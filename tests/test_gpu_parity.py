@@ -182,7 +182,7 @@ def test_hash_collisions_are_repaired(name, bits, expect, monkeypatch):
 @pytest.mark.parametrize("name", ["syn_k50_d2", "syn_k50_d1", "syn_k64_d3", "syn_k33_d2", "lowcx_k36_d1", "lowcx_k64_d3", "pal_k50_d2_p4t5",
                                   "q_k50_d2_p10", "fam_k48_d3", "multi_k50_d2_L", "ecoli_like_k50_d2"])
 def test_sketch_prefilter_changes_nothing(name, monkeypatch):
-    """Above 2**28 representatives every seed record carries a 4-byte sketch through its sort and k_verify dismisses
+    """Above 2**30 representatives every seed record carries a 4-byte sketch through its sort and k_verify dismisses
     partners whose sketches differ in more than d bases.  CORA_SKETCH=1 forces that path on the small fixtures: same
     bytes, same number of comparisons counted."""
     c, want = helpers.golden_case(name)
