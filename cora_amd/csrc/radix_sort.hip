@@ -3,10 +3,13 @@
 // through LDS so that every global store of a pass is a run of consecutive addresses.
 //
 // One pass = three small kernels over the [tiles][256] digit histogram plus the scatter:
-//   rs_hist      per-tile digit histogram                      (reads the digit word)
-//   rs_colsum / rs_chunkscan / rs_colscan   digit-major exclusive scan, row-coalesced
+//   rs_hist      per-tile digit histogram                      (reads the digit word; skipped when the producer counted)
+//   rs_colsum / rs_chunkscan / rs_colscan   digit-major exclusive scan, row-coalesced, loads batched
 //   rs_scatter   rank in LDS, stage, write                     (reads + writes every array)
 // HBM traffic per pass and record: 8 B (hist) + 2 x record bytes (scatter).
+// Tiles: 256 threads x 16 records for key-only records, 512 x 16 for records with a payload; the scatter hands runs of
+// consecutive tiles to one XCD (see rs_scatter).  A single-pass variant with decoupled look-back was measured slower on
+// this chip; tools/sortbench.cpp compares with copy / read ceilings and with rocPRIM.
 #include "radix_sort.hpp"
 #include <stdlib.h>
 
