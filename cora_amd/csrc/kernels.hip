@@ -873,28 +873,31 @@ __device__ __forceinline__ bool same_window(const DevParams &p, u64 a, u64 b)
     return (a - s) / w == (b - s) / w;
 }
 
-// looks in node `nd` for the item (src, tgt) whose dir/offsets equal `want`
-__device__ __forceinline__ bool find_item(const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
-                                          const u32 *__restrict__ node_start, u32 nd, u64 key, u32 want)
+// index of the item (src, tgt) of node `nd` whose dir/offsets equal `want`, or NO_ITEM
+constexpr u32 NO_ITEM = 0xFFFFFFFFu;
+__device__ __forceinline__ u32 find_item(const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
+                                         const u32 *__restrict__ node_start, u32 nd, u64 key, u32 want)
 {
     u32 a = node_start[nd], b = node_start[nd + 1];
+    const u32 end = b;
     while (a < b) {
         const u32 mid = (a + b) >> 1;
         if (item_key[mid] < key) a = mid + 1; else b = mid;
     }
-    const u32 end = node_start[nd + 1];
     for (; a < end && item_key[a] == key; a++)
-        if ((item_meta[a] & META_MATCH_MASK) == want) return true;
-    return false;
+        if ((item_meta[a] & META_MATCH_MASK) == want) return a;
+    return NO_ITEM;
 }
 
-// Diagonal block merge (HTS:1203-1270) for lists without tied targets: an item is absorbed when the
-// list one base upstream holds its diagonal predecessor (target one base back along its strand,
-// same direction, every offset one larger); a surviving item's block length is the length of the
-// diagonal run it heads.  Lists with tied targets are redone by the host in the reference's order.
-__global__ __launch_bounds__(256) void k_chain(DevParams p, const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
-                                               const u32 *__restrict__ head_flag, const u64 *__restrict__ node_of_excl,
-                                               const u32 *__restrict__ node_start, u32 n_nodes, u64 m, int16_t *__restrict__ blen)
+// Diagonal block merge (HTS:1203-1270) for lists without tied targets, as links: the successor of an item is the item
+// of the NEXT position's list that continues its diagonal (target one base further along its strand, same direction,
+// every offset one smaller, same compaction window).  An item that is somebody's successor is absorbed (block length -1);
+// a surviving item's block length is the length of the chain it heads (k_chain_walk).  One search per item instead of
+// one per chain step.  Lists with tied targets are redone by the host in the reference's order.
+__global__ __launch_bounds__(256) void k_chain_link(DevParams p, const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
+                                                    const u32 *__restrict__ head_flag, const u64 *__restrict__ node_of_excl,
+                                                    const u32 *__restrict__ node_start, u32 n_nodes, u64 m, u32 *__restrict__ succ,
+                                                    int16_t *__restrict__ blen)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
@@ -903,34 +906,25 @@ __global__ __launch_bounds__(256) void k_chain(DevParams p, const u64 *__restric
     const u64 src = key >> 32, tgt = key & 0xFFFFFFFFull;
     const u32 meta = item_meta[i];
     const u32 dir = meta & 1u, o1 = meta_o1(meta), o2 = meta_o2(meta), o3 = meta_o3(meta);
-    // predecessor?
-    if (nd > 0 && src > 0 && (item_key[node_start[nd - 1]] >> 32) == src - 1 && same_window(p, src - 1, src)) {
-        const bool can = dir ? true : (tgt > 0);
-        if (can) {
-            const u64 pt = dir ? tgt + 1 : tgt - 1;
-            const u32 want = meta_pack(dir, o1 + 1, o2 ? o2 + 1 : 0, o3 ? o3 + 1 : 0, 0, 0, 0);
-            if (o1 + 1 <= (u32)p.K && find_item(item_key, item_meta, node_start, nd - 1, ((src - 1) << 32) | pt, want)) {
-                blen[i] = -1;
-                return;
-            }
-        }
+    u32 s = NO_ITEM;
+    const u32 nn = nd + 1;
+    if (o1 > 1 && nn < n_nodes && (item_key[node_start[nn]] >> 32) == src + 1 && same_window(p, src, src + 1) && !(dir && tgt < 1)) {
+        const u64 nt = dir ? tgt - 1 : tgt + 1;
+        const u32 want = meta_pack(dir, o1 - 1, o2 ? o2 - 1 : 0, o3 ? o3 - 1 : 0, 0, 0, 0);
+        s = find_item(item_key, item_meta, node_start, nn, ((src + 1) << 32) | nt, want);
     }
-    u32 L = 1;
-    for (;;) {
-        if (o1 <= L) break;                                          // offset1 - distance must stay >= 1
-        const u32 nn = nd + L;
-        if (nn >= n_nodes) break;
-        if ((item_key[node_start[nn]] >> 32) != src + L) break;      // next position has no list
-        if (!same_window(p, src, src + L)) break;
-        if (dir && tgt < L) break;
-        const u64 nt = dir ? tgt - L : tgt + L;
-        const u32 want = meta_pack(dir, o1 - L, o2 ? o2 - L : 0, o3 ? o3 - L : 0, 0, 0, 0);
-        if (!find_item(item_key, item_meta, node_start, nn, ((src + L) << 32) | nt, want)) break;
-        L++;
-    }
-    blen[i] = (int16_t)L;
+    succ[i] = s;
+    if (s != NO_ITEM) blen[s] = -1;
 }
 
+__global__ __launch_bounds__(256) void k_chain_walk(const u32 *__restrict__ succ, u64 m, int16_t *__restrict__ blen)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m || blen[i] == -1) return;                 // (blen was zeroed before k_chain_link; only absorbed items hold -1)
+    u32 L = 1;
+    for (u32 j = succ[i]; j != NO_ITEM; j = succ[j]) L++; // at most K steps: offset 1 shrinks by one per link
+    blen[i] = (int16_t)L;
+}
 
 // ------------------------------------------------------------------ <Inexact> bytes on the device
 // Lists (nodes) whose final order needs no library sort are written by the GPU: a list of at most 16 items
@@ -1277,9 +1271,12 @@ void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_
     if (m) hipLaunchKernelGGL(k_node_starts, grid_for(m), dim3(256), 0, s, head_flag, node_of_excl, m, node_start);
 }
 void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u32 *head_flag,
-                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, int16_t *blen)
+                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen)
 {
-    if (m) hipLaunchKernelGGL(k_chain, grid_for(m), dim3(256), 0, s, p, item_key, item_meta, head_flag, node_of_excl, node_start, n_nodes, m, blen);
+    if (!m) return;
+    (void)hipMemsetAsync(blen, 0, m * sizeof(int16_t), s);
+    hipLaunchKernelGGL(k_chain_link, grid_for(m), dim3(256), 0, s, p, item_key, item_meta, head_flag, node_of_excl, node_start, n_nodes, m, succ, blen);
+    hipLaunchKernelGGL(k_chain_walk, grid_for(m), dim3(256), 0, s, succ, m, blen);
 }
 
 }  // namespace cora

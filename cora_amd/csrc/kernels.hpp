@@ -101,7 +101,7 @@ void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs
 void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr);
 void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start);
 void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u32 *head_flag,
-                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, int16_t *blen);
+                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ /* [m] scratch */, int16_t *blen);
 
 void launch_exact_size(hipStream_t s, int cw, const u32 *cls_entries, const u8 *merge_prev, u32 n_cls, u32 *size, DevCounters *ctr);
 void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cls_entries, const u64 *ent_off, const u32 *ent, const u8 *ent_dir,

@@ -305,7 +305,9 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         launch_node_starts(s, hf.p, nexcl.p, M, nstart.p);
         const u32 m32 = (u32)M;
         HIPQ(hipMemcpyAsync(nstart.p + n_nodes, &m32, sizeof(u32), hipMemcpyHostToDevice, s));
-        launch_chain(s, dp, kk.a, kk.c, hf.p, nexcl.p, nstart.p, (u32)n_nodes, M, blen.p);
+        DBuf<u32> succ;
+        RCQ(succ.alloc(M));
+        launch_chain(s, dp, kk.a, kk.c, hf.p, nexcl.p, nstart.p, (u32)n_nodes, M, succ.p, blen.p);
         HIPQ(hipGetLastError());
         // ---- bytes: lists the device can order itself are written here; the others go to the host (kernels.hip) ----
         const int cw = job->prm.chr_short ? 2 : 1;
