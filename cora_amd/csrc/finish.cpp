@@ -282,7 +282,7 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
         return wl != 0 && (src_of(nd - 1) - g.gstart[ci]) / wl != (src_of(nd) - g.gstart[ci]) / wl;
     };
     int T = n_threads < 1 ? 1 : n_threads;
-    if (r.key.size() < 200000) T = 1;
+    if (r.key.size() < 8192) T = 1;
     std::vector<size_t> cut(1, 0);
     for (int t = 1; t < T; t++) {
         // split by items, not nodes, to balance
