@@ -489,17 +489,22 @@ __global__ __launch_bounds__(256) void k_mask_count(const u64 *__restrict__ mask
     if (threadIdx.x == 0) blk_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
+// Dense masks (class heads: 96 % of the bits are set): a wave walks its 64 words, lane l takes bit l, so that consecutive
+// lanes store consecutive outputs (one thread per word, each storing its own 60 positions, ran at a third of this rate).
 __global__ __launch_bounds__(256) void k_mask_emit(const u64 *__restrict__ mask, u64 n_words, const u64 *__restrict__ blk_off,
                                                    u32 *__restrict__ pos)
 {
     __shared__ u32 l4[4];
-    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
-    u64 bal = (w < n_words) ? mask[w] : 0;
-    u64 at = blk_off[blockIdx.x] + block_excl_scan_u32((u32)__popcll(bal), l4, nullptr);
-    while (bal) {
-        const int b = __ffsll((long long)bal) - 1;
-        pos[at++] = (u32)(w * 64 + b);
-        bal &= bal - 1;
+    const int lane = threadIdx.x & 63;
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;          // this lane's word; its wave's words are w - lane .. w - lane + 63
+    const u64 mine = (w < n_words) ? mask[w] : 0;
+    const u32 excl = block_excl_scan_u32((u32)__popcll(mine), l4, nullptr);
+    const u64 at0 = blk_off[blockIdx.x];
+    const u64 lt = (1ull << lane) - 1ull;
+    for (int k = 0; k < 64; k++) {
+        const u64 word = __shfl(mine, k, 64);
+        const u32 before = __shfl(excl, k, 64);
+        if ((word >> lane) & 1ull) pos[at0 + before + (u32)__popcll(word & lt)] = (u32)((w - lane + k) * 64 + lane);
     }
 }
 
@@ -514,17 +519,22 @@ __global__ __launch_bounds__(256) void k_bitmap_count(const u32 *__restrict__ bi
     if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
 }
 
+// (dense as well: nearly every valid window is a representative; bit 31-i of word w = position 32w+i)
 __global__ __launch_bounds__(256) void k_bitmap_emit(const u32 *__restrict__ bits, u64 n_words, const u64 *__restrict__ block_off,
                                                      u32 *__restrict__ out, u32 base)
 {
     __shared__ u32 l4[4];
+    const int lane = threadIdx.x & 63;
     const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
-    u32 word = (w < n_words) ? bits[w] : 0u;
-    u64 at = block_off[blockIdx.x] + block_excl_scan_u32((u32)__popc(word), l4, nullptr);
-    while (word) {
-        const int lz = __clz((int)word);
-        out[at++] = base + (u32)(w * 32 + lz);
-        word &= ~(0x80000000u >> lz);
+    const u32 mine = (w < n_words) ? bits[w] : 0u;
+    const u32 excl = block_excl_scan_u32((u32)__popc(mine), l4, nullptr);
+    const u64 at0 = block_off[blockIdx.x];
+    const u64 lt = (1ull << lane) - 1ull;
+    for (int k = 0; k < 64; k += 2) {                            // two words = 64 positions per step
+        const u32 w0 = __shfl(mine, k, 64), w1 = __shfl(mine, k + 1, 64);
+        const u32 before = __shfl(excl, k, 64);
+        const u64 both = (u64)__brev(w0) | ((u64)__brev(w1) << 32);   // bit l = position 32 * (first word) + l
+        if ((both >> lane) & 1ull) out[at0 + before + (u32)__popcll(both & lt)] = base + (u32)((w - lane + k) * 32 + lane);
     }
 }
 
