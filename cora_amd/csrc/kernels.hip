@@ -636,6 +636,21 @@ __global__ __launch_bounds__(256) void k_seed_codes(DevParams p, const u64 *__re
     out[r] = ((u64)(fw <= rc ? fw : rc) << 32) | g;          // canonical code (HTS:2732-2744)
 }
 
+// seed_code with the seed count known at compile time: the left positions s, s+NS, ... are constants (all inside the first
+// 32 bases), the right ones are constants counted from the K-mer's end, so `tail` holds the last 32 bases right-aligned.
+template <int NS>
+__device__ __forceinline__ u32 seed_code_fixed(u64 hi, u64 tail, int s /*0-based seed*/, int q)
+{
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (j < q) v = (v << 2) | ((u32)(hi >> (62 - 2 * (s + NS * j))) & 3u);
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (j >= q) v = (v << 4) | 3u;
+#pragma unroll
+    for (int j = 7; j >= 0; j--) if (j < q) v = (v << 2) | ((u32)(tail >> (2 * (s + NS * j))) & 3u);
+    return v;
+}
+
 // All seeds of a run in one pass over the representatives: one window load, NS codes, and -- because a block covers
 // exactly one 4096-record tile of the key-only sort -- the per-tile histogram of each code array's first sort digit
 // (bits 32..39 of the record = low byte of the code), which saves that sort its first histogram pass.
@@ -661,9 +676,11 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
         const u32 g = reps[r];
         u64 hi, lo;
         load_window(p, pk, g, hi, lo);
+        const int sh = 128 - 2 * p.K;                     // 0 .. 62
+        const u64 tail = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
         u32 fwc[NS];
 #pragma unroll
-        for (int s = 0; s < NS; s++) fwc[s] = seed_code(p, hi, lo, s + 1);
+        for (int s = 0; s < NS; s++) fwc[s] = seed_code_fixed<NS>(hi, tail, s, p.seed_q);
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const u32 fw = fwc[s], rc = rc_code(fw);
