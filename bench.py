@@ -130,7 +130,10 @@ def main():
     t0 = time.perf_counter()
     sc_ms, sc_n, sc_bytes = 0.0, 0, 0
     for _ in range(a.steps):
+        ts = time.perf_counter()
         run()
+        if os.environ.get("CORA_TRACE"):
+            print("[bench] step wall %.3f ms" % ((time.perf_counter() - ts) * 1e3), file=sys.stderr)
         st = job.stats()
         sc_ms += st["ms_sort_scatter"]; sc_n += st["n_sort_scatter"]; sc_bytes += st["sort_scatter_bytes"]
     sync()

@@ -229,6 +229,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     st.ms_sort_scatter = job->sort_timing.scatter_ms;
     st.n_sort_scatter = job->sort_timing.scatter_launches;
     st.sort_scatter_bytes = job->sort_timing.scatter_bytes;
+    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] run %.3f ms; device pool: %zu blocks, %zu hipMalloc calls so far (%.1f MB)\n", st.ms_total,
+                                      job->pool.blocks.size(), job->pool.n_malloc, job->pool.malloc_bytes / 1e6);
     return 0;
 }
 

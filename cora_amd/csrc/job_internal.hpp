@@ -40,6 +40,7 @@ inline int fail(int code, const char *fmt, ...)
 struct DevPool {
     struct Block { void *p; size_t bytes; bool free; };
     std::vector<Block> blocks;
+    size_t n_malloc = 0, malloc_bytes = 0;               // since the pool was made (CORA_TRACE prints them per run)
     void *get(size_t bytes)
     {
         bytes = (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
@@ -54,6 +55,7 @@ struct DevPool {
             if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
         }
         blocks.push_back({p, bytes, false});
+        n_malloc++; malloc_bytes += bytes;
         return p;
     }
     void put(void *p)
