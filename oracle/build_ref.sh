@@ -13,3 +13,15 @@ mkdir -p "$here/_ref"
 g++ -static -O3 -w -o "$here/_ref/homTable_setup"   "$src" -fopenmp 2>/dev/null
 g++ -DCHR_SHORT -static -O3 -w -o "$here/_ref/homTable_setup_L" "$src" -fopenmp 2>/dev/null
 echo "built $here/_ref/homTable_setup and homTable_setup_L"
+# The consumer's table loaders (mappingInference.cpp:554-723, 1084-1153) behind a dump harness of our own
+# (ref_loader_main.cpp includes the reference source from where it lies).  _L = 2-byte contig ids, _e3 = room for
+# three offsets per item (-DED_THREE, mappingInference.cpp:20-23; the reference's makefile builds the same variants).
+msrc="${CORA_REFERENCE:-/root/reference}/mappingInference.cpp"
+if [ -f "$msrc" ]; then
+  for v in "" "_L" "_e3" "_L_e3"; do
+    fl=""; case "$v" in *_L*) fl="$fl -DCHR_SHORT";; esac; case "$v" in *_e3) fl="$fl -DED_THREE";; esac
+    g++ -O2 -w $fl -DCORA_REF_SRC="\"$msrc\"" -I"$here" -o "$here/_ref/ref_loader$v" "$here/ref_loader_main.cpp" &
+  done
+  wait
+  echo "built $here/_ref/ref_loader{,_L,_e3,_L_e3}"
+fi
