@@ -24,6 +24,8 @@ EXPORTS = [
     "cora_hip_radix_sort", "cora_hip_test_sort_host", "cora_hip_test_pack", "cora_hip_test_kmers",
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
     "cora_hip_shard_slot_import", "cora_hip_shard_slot_ptr", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
+    "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
+    "cora_hip_tables_export", "cora_hip_tables_destroy",
 ]
 
 
@@ -43,6 +45,16 @@ class Stats(C.Structure):
         "ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total", "ms_sort_scatter")] + [
         ("n_sort_scatter", C.c_uint32), ("sort_scatter_bytes", C.c_uint64), ("hash_mixed_runs", C.c_uint64),
         ("full_key_fallback", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class TablesInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "exact_records", "exact_entries", "inexact_nodes", "inexact_items", "hub_positions", "device_bytes",
+        "serial_hub_replay")] + [("d", C.c_int32), ("chr_short", C.c_int32)] + [(n, C.c_float) for n in (
+        "ms_parse", "ms_lookups", "ms_hubs", "ms_total")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -92,6 +104,14 @@ def lib():
         L.cora_hip_shard_slot_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cora_hip_shard_get_first_singleton.argtypes = [C.c_void_p, C.c_void_p]
         L.cora_hip_shard_set_first_singleton.argtypes = [C.c_void_p, C.c_uint64]
+        L.cora_hip_tables_load.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint64,
+                                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.cora_hip_tables_from_job.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.cora_hip_tables_get_info.argtypes = [C.c_void_p, C.POINTER(TablesInfo)]
+        L.cora_hip_tables_array_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cora_hip_tables_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+        L.cora_hip_tables_destroy.argtypes = [C.c_void_p]
+        L.cora_hip_tables_destroy.restype = None
         _lib = L
     return _lib
 

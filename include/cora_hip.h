@@ -127,6 +127,68 @@ int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const void *src_devi
 int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
 int cora_hip_shard_set_first_singleton(cora_hip_job *job, uint64_t key);
 
+/* ---- the consumer side of the tables: load <Exact>/<Inexact> into HBM ----
+ * MI = /root/reference/mappingInference.cpp.  Replaces LoadHomologyTables (MI:1084-1153), i.e. LoadEquivClasses
+ * (MI:654-723), LoadInexactHomologies incl. the reverse-lookup walk (MI:554-651) and the position hubs equivHub /
+ * homHub (MI:537-538, 1093-1152).  The lists become CSR arrays, the two hash maps become dense u32 arrays over the
+ * concatenated contigs (index = sum of earlier contig lengths + pos - 1); hub VALUES are the reference's 1-based list
+ * indices and 0 = no entry, which is how every reader of the maps treats an absent key (MI:1841-1848, 6620-6630).
+ * Everything is computed on the GPU from the table bytes; results equal the reference's loaders field by field. */
+typedef struct cora_hip_tables cora_hip_tables;   /* opaque */
+
+enum cora_hip_tables_array {            /* element type, length */
+    CORA_TA_EQ_CHR = 0,                 /* u16  records        equivClassNode::chrCode (MI:520-531) */
+    CORA_TA_EQ_POS,                     /* u32  records        ::chrPos */
+    CORA_TA_EQ_BLOCK,                   /* u32  records        ::blockLen */
+    CORA_TA_EQ_OFF,                     /* u64  records + 1    entries of record i are [off[i], off[i+1])  (::list, ::listSize) */
+    CORA_TA_EQI_DIR,                    /* u8   entries        eqItem::dir (MI:508-517) */
+    CORA_TA_EQI_CHR,                    /* u16  entries */
+    CORA_TA_EQI_POS,                    /* u32  entries */
+    CORA_TA_HM_CHR,                     /* u16  nodes          emHomClassNode::chrCode (MI:488-499) */
+    CORA_TA_HM_POS,                     /* u32  nodes */
+    CORA_TA_HM_OFF,                     /* u64  nodes + 1 */
+    CORA_TA_HM_MAXREV,                  /* u8   nodes          ::maxRevLookup (MI:638-650) */
+    CORA_TA_HMI_DIR,                    /* u8   items          emHomItem::dir, 1 bit (MI:475-486) */
+    CORA_TA_HMI_CHR,                    /* u16  items */
+    CORA_TA_HMI_POS,                    /* u32  items */
+    CORA_TA_HMI_BLOCK,                  /* u8   items          ::blockLen, 7 bits */
+    CORA_TA_HMI_OFFS,                   /* u8   items * d      ::offsetList[0..d) */
+    CORA_TA_EQUIV_HUB,                  /* u32  hub positions  equivHub (MI:537) */
+    CORA_TA_HOM_HUB,                    /* u32  hub positions  homHub (MI:538) */
+    CORA_TA_COUNT
+};
+
+typedef struct cora_hip_tables_info {
+    uint64_t exact_records, exact_entries;   /* equivClassListSize, sum of listSize */
+    uint64_t inexact_nodes, inexact_items;   /* emHomClassListSize, sum of listSize */
+    uint64_t hub_positions;                  /* sum of contig lengths */
+    uint64_t device_bytes;                   /* HBM held by the loaded image */
+    uint64_t serial_hub_replay;              /* 1 if some hub position was both copied from and copied to (no table builder
+                                                writes that): homHub was then filled in the reference's sequential order */
+    int32_t d, chr_short;
+    float ms_parse, ms_lookups, ms_hubs, ms_total;   /* HIP events; table bytes already in HBM when the clock starts */
+} cora_hip_tables_info;
+
+/* exact / inexact: the two files' bytes (host memory); *_count: the number in "<table>.itemCount" (MI:559-567, 657-665).
+ * contig_len[n_contigs]: contig lengths in .fai order.  exact_only != 0 is the loading of the BEST mapping modes
+ * (MI:1090-1093, 1139-1152): no inexact table, equivHub over the representatives' ranges only.
+ * Errors (non-zero, text in cora_hip_last_error): 87/88/89/90 are the reference's exit codes for unreadable inputs and
+ * are returned by the file-level callers; this function returns 91 for bytes that do not parse to exactly *_count
+ * records, 92 for nodes out of (contig, position) order or without items, 93 for positions outside the contigs
+ * (the reference's maps would take any key; the dense hubs cannot). */
+int cora_hip_tables_load(const uint8_t *exact, size_t exact_bytes, uint64_t exact_count,
+                         const uint8_t *inexact, size_t inexact_bytes, uint64_t inexact_count,
+                         const uint32_t *contig_len, int32_t n_contigs, int32_t d, int32_t chr_short, int32_t exact_only,
+                         cora_hip_tables **out);
+/* Same, straight from the tables of a job's last run (no trip through files); contig lengths come from the job. */
+int cora_hip_tables_from_job(const cora_hip_job *job, int32_t exact_only, cora_hip_tables **out);
+int cora_hip_tables_get_info(const cora_hip_tables *t, cora_hip_tables_info *out);
+/* Device address, element count and element size of one array of the loaded image (for the caller's own kernels). */
+int cora_hip_tables_array_ptr(const cora_hip_tables *t, int which, const void **device_ptr, uint64_t *n_elems, uint32_t *elem_bytes);
+/* Copies one array to host memory; dst_bytes must be at least n_elems * elem_bytes. */
+int cora_hip_tables_export(const cora_hip_tables *t, int which, void *dst_host, uint64_t dst_bytes);
+void cora_hip_tables_destroy(cora_hip_tables *t);
+
 /* ---- stage-level entry points (used by the parity tests and the benchmark) ---- */
 
 /* Stable LSD radix sort of n records on device memory, keyed on bits

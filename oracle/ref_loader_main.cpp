@@ -25,7 +25,9 @@ int main(int argc, char **argv)
     for (int c = 1; c <= nc; c++) { len[c] = strtoull(argv[5 + c], 0, 10); start[c + 1] = start[c] + len[c]; }
     unsigned long long G = start[nc + 1];
 
-    LoadHomologyTables(argv[1], argv[2], K, d, ALL_MAPPING_MODE);
+    // CORA_REF_EXACT_ONLY=1: the loading of the BEST mapping modes (no inexact table, mappingInference.cpp:1090-1093, 1139-1152)
+    const char *eo = getenv("CORA_REF_EXACT_ONLY");
+    LoadHomologyTables(argv[1], argv[2], K, d, (eo && eo[0] == '1') ? BEST_MAPPING_MODE : ALL_MAPPING_MODE);
 
     loader_dump D;
     memset(&D, 0, sizeof D);

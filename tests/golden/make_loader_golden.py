@@ -181,8 +181,9 @@ def contig_lengths(inp):
     return [len(s) for _, s in make_golden.INPUTS[inp]()]
 
 
-def run_ref(L, d, K, ex, inx, lens, out):
+def run_ref(L, d, K, ex, inx, lens, out, exact_only=False):
     r = subprocess.run([ref_loader(L, d), ex, inx, str(K), str(d), out] + [str(x) for x in lens],
+                       env=dict(os.environ, CORA_REF_EXACT_ONLY="1" if exact_only else "0"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise SystemExit("ref_loader failed (%d): %s" % (r.returncode, r.stdout[-2000:]))
@@ -230,8 +231,10 @@ def main():
         write_tables(dirn, records, nodes, L, d)
         out = os.path.join(dirn, "reference.dump")
         run_ref(L, d, 50, os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), lens, out)
+        eo = os.path.join(tmp, name + ".exact_only.dump")
+        run_ref(L, d, 50, os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), lens, eo, exact_only=True)
         manifest["loader_cases"][name] = {"L": L, "d": d, "contig_lengths": lens, "records": len(records), "nodes": len(nodes),
-                                          "loader_sha256": sha256(out)}
+                                          "loader_sha256": sha256(out), "loader_exact_only_sha256": sha256(eo)}
         print("%-22s %4d records %5d nodes  loaded image %8d B" % (name, len(records), len(nodes), os.path.getsize(out)), flush=True)
     json.dump(manifest, open(mpath, "w"), indent=1, sort_keys=True)
     shutil.rmtree(tmp)

@@ -96,3 +96,56 @@ def assert_same_tables(got_ex, got_inx, want_dir, label=""):
         wc = read(os.path.join(want_dir, fn + ".itemCount"))
         gc = read(got + ".itemCount")
         assert gc == wc, "%s %s.itemCount: got %r want %r" % (label, fn, gc, wc)
+
+
+# ---- table loaders ----
+LOADER_ORACLE = os.path.join(ORACLE_DIR, "loader_oracle")
+LOADER_CASES = os.path.join(GOLDEN, "loader_cases")
+
+
+def build_loader_oracle():
+    src = os.path.join(ORACLE_DIR, "loader_oracle.c")
+    if not os.path.exists(LOADER_ORACLE) or os.path.getmtime(LOADER_ORACLE) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "loader_oracle"], stdout=subprocess.DEVNULL)
+    return LOADER_ORACLE
+
+
+def run_loader_oracle(exact, inexact, d, lens, out, L=False, exact_only=False):
+    cmd = [build_loader_oracle()] + (["-L"] if L else []) + (["--exact-only"] if exact_only else [])
+    r = subprocess.run(cmd + [exact, inexact, str(d), out] + [str(x) for x in lens], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return r
+
+
+def read_dump(path):
+    """-> the 18 arrays of oracle/loader_dump.h as numpy arrays (dtypes from cora_amd.tables.ARRAYS)."""
+    import numpy as np
+    from cora_amd.tables import ARRAYS
+    raw = read(path)
+    out, at = [], 0
+    for name, dt in ARRAYS:
+        nbytes = int.from_bytes(raw[at:at + 8], "little")
+        at += 8
+        out.append(np.frombuffer(raw, dtype=dt, count=nbytes // np.dtype(dt).itemsize, offset=at))
+        at += nbytes
+    assert at == len(raw), "dump has trailing bytes"
+    return out
+
+
+def dump_sha256(arrays):
+    """sha256 of the dump file these arrays would make (u64 byte count + data, in order)."""
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(int(a.nbytes).to_bytes(8, "little"))
+        h.update(memoryview(a).cast("B") if a.nbytes else b"")
+    return h.hexdigest()
+
+
+def assert_same_arrays(got, want, label=""):
+    import numpy as np
+    from cora_amd.tables import ARRAYS
+    for (name, _), g, w in zip(ARRAYS, got, want):
+        assert len(g) == len(w), "%s %s: %d elements, want %d" % (label, name, len(g), len(w))
+        if not np.array_equal(g, w):
+            i = int(np.nonzero(g != w)[0][0])
+            raise AssertionError("%s %s differs first at [%d]: got %d want %d (%d of %d differ)" % (
+                label, name, i, g[i], w[i], int((g != w).sum()), len(w)))
