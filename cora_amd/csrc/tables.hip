@@ -233,6 +233,7 @@ __global__ void k_hub_nodes(const u16 *__restrict__ chr, const u32 *__restrict__
     hom_hub[g] = (u32)(L + 1);                                           // homHub[chr][pos] = i (MI:1096-1100); positions are distinct
 }
 
+constexpr u32 SPAN_LANES = 8;
 struct ExactView { const u16 *chr; const u32 *pos; const u32 *block; const u64 *off; const u8 *i_dir; const u16 *i_chr; const u32 *i_pos; u64 n, m; };
 
 // Which record an entry belongs to: rec_of[k] for k < m, filled from the offsets.
@@ -243,21 +244,22 @@ __global__ void k_entry_owner(const u64 *__restrict__ off, u64 n, u32 *__restric
     for (u64 k = off[i]; k < off[i + 1]; k++) rec_of[k] = (u32)i;
 }
 
-// One wave per "span": spans [0, n) are the representatives' ranges, spans [n, n + m) the members'.
+// SPAN_LANES lanes per "span" (most blocks are a few positions long; a long one is strided over by its lanes):
+// spans [0, n) are the representatives' ranges, spans [n, n + m) the members'.
 // phase 0: equivHub (atomic max of the 1-based record index) and the bitmap of positions copies write to.
 // phase 1: is any source also a target?  then the copies.      phase 2: did every copy keep its value?
 template <int PHASE>
 __global__ __launch_bounds__(256) void k_hub_spans(ExactView x, const u32 *__restrict__ rec_of, Contigs c, int exact_only,
                                                    u32 *__restrict__ equiv_hub, u32 *__restrict__ hom_hub, u32 *__restrict__ target_mask, LoadCounters *ctr)
 {
-    const u64 span = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u32 lane = threadIdx.x & 63;
+    const u64 span = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / SPAN_LANES;
+    const u32 lane = threadIdx.x % SPAN_LANES;
     const u64 n_spans = exact_only ? x.n : x.n + x.m;
     if (span >= n_spans) return;
     if (span < x.n) {
         if (PHASE != 0) return;
         const u32 rc = x.chr[span], rp = x.pos[span], bl = x.block[span];
-        for (u32 j = lane; j < bl; j += 64) {
+        for (u32 j = lane; j < bl; j += SPAN_LANES) {
             u64 g;
             if (!hub_index(c, rc, rp + j, g)) { atomicAdd(&ctr->err_range, 1u); continue; }
             atomicMax(&equiv_hub[g], (u32)(span + 1));                   // MI:1108-1111
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void k_hub_spans(ExactView x, const u32 *__res
     const u32 rc = x.chr[i], rp = x.pos[i], bl = x.block[i];
     const u32 mc = x.i_chr[k], mp = x.i_pos[k];
     const bool fwd = x.i_dir[k] == 0;                                    // MI:1116
-    for (u32 j = lane; j < bl; j += 64) {
+    for (u32 j = lane; j < bl; j += SPAN_LANES) {
         u64 t, s;
         if (!hub_index(c, mc, fwd ? mp + j : mp - j, t) || !hub_index(c, rc, rp + j, s)) { if (PHASE == 0) atomicAdd(&ctr->err_range, 1u); continue; }
         if (PHASE == 0) {
@@ -450,7 +452,7 @@ int load_impl(cora_hip_tables *t, const u8 *exact, size_t exact_bytes, u64 exact
         HIPQ(hipMemsetAsync(tmask.p, 0, (t->G / 32 + 1) * 4, s));
         hipLaunchKernelGGL(k_entry_owner, dim3(grid_for(t->n_eq, 256)), dim3(256), 0, s, t->eq_off.p, t->n_eq, rec_of.p);
         const u64 spans = t->exact_only ? t->n_eq : t->n_eq + t->m_eq;
-        const u32 g = grid_for(spans, 4);                                // 4 waves per workgroup
+        const u32 g = grid_for(spans, 256 / SPAN_LANES);
         hipLaunchKernelGGL((k_hub_spans<0>), dim3(g), dim3(256), 0, s, x, rec_of.p, ctg, t->exact_only, t->equiv_hub.p, t->hom_hub.p, tmask.p, ctr.p);
         if (!t->exact_only && t->m_eq) {
             hipLaunchKernelGGL((k_hub_spans<1>), dim3(g), dim3(256), 0, s, x, rec_of.p, ctg, 0, t->equiv_hub.p, t->hom_hub.p, tmask.p, ctr.p);

@@ -1,4 +1,4 @@
-/* TEST INFRASTRUCTURE ONLY -- never linked or called by the product (see oracle/README.md).
+/* TEST INFRASTRUCTURE ONLY -- never linked or called by the product (DESIGN.md sections 2 and 8: only tests/, smoke() and benchmarks may build or run it).
  *
  * loader_oracle.c: CPU restatement of how the consumer of the two homology tables loads them
  * (MI = /root/reference/mappingInference.cpp), the row SURVEY.md section 8(f).1 names as the next one:

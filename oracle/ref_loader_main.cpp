@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md): drives the REAL reference's homology-table loaders and
+// TEST INFRASTRUCTURE ONLY (DESIGN.md sections 2 and 8): drives the REAL reference's homology-table loaders and
 // dumps what they built, so that oracle/loader_oracle.c and the HIP loader can be pinned against them.
 //
 // The reference source is compiled from where it lies (build_ref.sh passes its path as CORA_REF_SRC); nothing
