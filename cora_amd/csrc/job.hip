@@ -276,6 +276,23 @@ extern "C" int cora_hip_radix_sort(uint64_t *key_hi, uint64_t *key_lo, uint32_t 
     return 0;
 }
 
+extern "C" int cora_hip_test_list_sort(uint32_t *elems, uint64_t n, int forced_depth)
+{
+    g_err.clear();
+    if (g_device < 0) return fail(2, "cora_hip_init has not been called");
+    if (!n) return 0;
+    HIPQ(hipSetDevice(g_device));
+    PoolScope no_pool(nullptr);
+    DBuf<u32> d;
+    RCQ(d.alloc(n));
+    HIPQ(hipMemcpy(d.p, elems, n * sizeof(u32), hipMemcpyHostToDevice));
+    launch_test_list_sort(nullptr, d.p, n, forced_depth);
+    HIPQ(hipGetLastError());
+    HIPQ(hipDeviceSynchronize());
+    HIPQ(hipMemcpy(elems, d.p, n * sizeof(u32), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val, uint64_t n, int bit_lo, int bit_hi)
 {
     if (g_device < 0) return fail(102, "cora_hip_init has not succeeded");

@@ -539,6 +539,10 @@ __global__ __launch_bounds__(256) void k_bitmap_emit(const u32 *__restrict__ bit
 }
 
 // ------------------------------------------------------------------ exact table pieces
+// Classes, records and lists are handled one per thread; one longer than this (Mbp of tandem repeats make classes of
+// 10^6 entries) is queued in LDS and then shared by the whole workgroup.
+constexpr u32 COOP_MIN = 128;
+
 // cls[k] = rep<<32 | class index, sorted by rep.  flags: bit0 palindrome, bit1 flip, bit2 rep strand, bit3 leading.
 __global__ __launch_bounds__(256) void k_class_info(const u64 *__restrict__ rec, const u32 *__restrict__ class_start,
                                                     const u64 *__restrict__ cls, u32 n_cls, const DevCounters *__restrict__ ctr,
@@ -566,17 +570,41 @@ __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ r
                                                        const u32 *__restrict__ cls_flags, const u64 *__restrict__ ent_off,
                                                        u32 *__restrict__ ent, u8 *__restrict__ ent_dir)
 {
+    __shared__ u32 s_big[256];
+    __shared__ u32 s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
     const u32 k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_cls) return;
-    const u32 c = (u32)cls[k];
-    const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[k];
-    u64 o = ent_off[k];
-    for (u32 j = 0; j < m; j++) {
-        const u32 g = gpos[st + j];
-        if (fl & 1u) {
-            ent[o] = g; ent_dir[o] = 0; ent[o + 1] = g; ent_dir[o + 1] = 1; o += 2;
+    if (k < n_cls) {
+        const u32 c = (u32)cls[k];
+        const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[k];
+        if (m > COOP_MIN) {
+            s_big[atomicAdd(&s_nbig, 1u)] = k;                  // a long class (low-complexity sequence): the whole block shares it
         } else {
-            ent[o] = g; ent_dir[o] = (u8)(((u32)rec[st + j] & 1u) ^ ((fl >> 1) & 1u)); o++;
+            u64 o = ent_off[k];
+            for (u32 j = 0; j < m; j++) {
+                const u32 g = gpos[st + j];
+                if (fl & 1u) {
+                    ent[o] = g; ent_dir[o] = 0; ent[o + 1] = g; ent_dir[o + 1] = 1; o += 2;
+                } else {
+                    ent[o] = g; ent_dir[o] = (u8)(((u32)rec[st + j] & 1u) ^ ((fl >> 1) & 1u)); o++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const u32 nbig = s_nbig;
+    for (u32 b = 0; b < nbig; b++) {
+        const u32 kb = s_big[b], c = (u32)cls[kb];
+        const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[kb];
+        const u64 o = ent_off[kb];
+        for (u32 j = threadIdx.x; j < m; j += 256) {
+            const u32 g = gpos[st + j];
+            if (fl & 1u) {
+                ent[o + 2ull * j] = g; ent_dir[o + 2ull * j] = 0; ent[o + 2ull * j + 1] = g; ent_dir[o + 2ull * j + 1] = 1;
+            } else {
+                ent[o + j] = g; ent_dir[o + j] = (u8)(((u32)rec[st + j] & 1u) ^ ((fl >> 1) & 1u));
+            }
         }
     }
 }
@@ -587,21 +615,49 @@ __global__ __launch_bounds__(256) void k_class_merge(const u64 *__restrict__ cls
                                                      const u64 *__restrict__ ent_off, const u32 *__restrict__ ent,
                                                      const u8 *__restrict__ ent_dir, u8 *__restrict__ merge_prev)
 {
+    __shared__ u32 s_big[256];
+    __shared__ u32 s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
     const u32 c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_cls) return;
-    u8 ok = 0;
-    if (c > 0 && (cls[c] >> 32) == (cls[c - 1] >> 32) + 1 && cls_entries[c] == cls_entries[c - 1]) {
-        const u64 oa = ent_off[c - 1], ob = ent_off[c];
-        const u32 ne = cls_entries[c];
-        ok = 1;
-        for (u32 k = 1; k < ne; k++) {
-            const u8 da = ent_dir[oa + k];
-            if (da != ent_dir[ob + k]) { ok = 0; break; }
-            const u32 want = da ? ent[oa + k] - 1u : ent[oa + k] + 1u;
-            if (ent[ob + k] != want) { ok = 0; break; }
+    if (c < n_cls) {
+        u8 ok = 0;
+        if (c > 0 && (cls[c] >> 32) == (cls[c - 1] >> 32) + 1 && cls_entries[c] == cls_entries[c - 1]) {
+            const u64 oa = ent_off[c - 1], ob = ent_off[c];
+            const u32 ne = cls_entries[c];
+            if (ne > COOP_MIN) {
+                s_big[atomicAdd(&s_nbig, 1u)] = c;
+            } else {
+                ok = 1;
+                for (u32 k = 1; k < ne; k++) {
+                    const u8 da = ent_dir[oa + k];
+                    if (da != ent_dir[ob + k]) { ok = 0; break; }
+                    const u32 want = da ? ent[oa + k] - 1u : ent[oa + k] + 1u;
+                    if (ent[ob + k] != want) { ok = 0; break; }
+                }
+            }
         }
+        merge_prev[c] = ok;
     }
-    merge_prev[c] = ok;
+    __syncthreads();
+    const u32 nbig = s_nbig;
+    for (u32 b = 0; b < nbig; b++) {                             // two long neighbours of equal size: compared by the whole block
+        const u32 cb = s_big[b];
+        const u64 oa = ent_off[cb - 1], ob = ent_off[cb];
+        const u32 ne = cls_entries[cb];
+        int ok = 1;
+        for (u32 base = 1; base < ne; base += 256) {
+            const u32 k = base + threadIdx.x;
+            int mine = 1;
+            if (k < ne) {
+                const u8 da = ent_dir[oa + k];
+                const u32 want = da ? ent[oa + k] - 1u : ent[oa + k] + 1u;
+                mine = (da == ent_dir[ob + k]) && (ent[ob + k] == want);
+            }
+            if (!__syncthreads_and(mine)) { ok = 0; break; }      // uniform result: every thread leaves together
+        }
+        if (threadIdx.x == 0) merge_prev[cb] = (u8)ok;
+    }
 }
 
 // ------------------------------------------------------------------ seeds
@@ -953,12 +1009,131 @@ __global__ __launch_bounds__(256) void k_chain_walk(const u32 *__restrict__ succ
     blen[i] = (int16_t)L;
 }
 
+// ------------------------------------------------------------------ libstdc++'s std::sort, on the device
+// The reference orders every list by decreasing block length with std::sort (HTS:1368, 1110-1113).  Above 16 items that
+// is introsort -- median-of-3 quicksort to depth 2 lg n, heapsort below that, one insertion pass at the end (GCC
+// bits/stl_algo.h, bits/stl_heap.h) -- which is not stable, so the order of equal block lengths is whatever exactly that
+// algorithm makes of the incoming (target) order.  It is deterministic, so one thread per list runs exactly that
+// algorithm.  Elements are u32: (block length + 1) << 25 | index in the list; only the top 7 bits are compared.
+// The recursion of __introsort_loop on the right part becomes an explicit stack: the parts are disjoint, so the order in
+// which they are finished does not matter.  Restated on the CPU in oracle/hts_oracle.c (ss_*), which tests pin against
+// the real std::sort; tests/test_gpu_parity.py compares this one with it through cora_hip_test_list_sort.
+constexpr int DS_KEY_SHIFT = 25;
+__device__ __forceinline__ bool ds_less(u32 x, u32 y) { return (x >> DS_KEY_SHIFT) > (y >> DS_KEY_SHIFT); }
+__device__ __forceinline__ void ds_swap(u32 *e, long a, long b) { const u32 t = e[a]; e[a] = e[b]; e[b] = t; }
+
+__device__ void ds_adjust_heap(u32 *e, long hole, long len, u32 value)       // __adjust_heap + __push_heap
+{
+    const long top = hole;
+    long second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (ds_less(e[second], e[second - 1])) second--;
+        e[hole] = e[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        e[hole] = e[second - 1];
+        hole = second - 1;
+    }
+    long parent = (hole - 1) / 2;
+    while (hole > top && ds_less(e[parent], value)) {
+        e[hole] = e[parent];
+        hole = parent; parent = (hole - 1) / 2;
+    }
+    e[hole] = value;
+}
+
+__device__ void ds_heap_sort(u32 *e, long len)                                // __partial_sort(first, last, last)
+{
+    if (len >= 2) {
+        for (long parent = (len - 2) / 2;; parent--) {
+            ds_adjust_heap(e, parent, len, e[parent]);
+            if (parent == 0) break;
+        }
+    }
+    for (long last = len; last > 1;) {
+        --last;
+        const u32 value = e[last];
+        e[last] = e[0];
+        ds_adjust_heap(e, 0, last, value);
+    }
+}
+
+__device__ __forceinline__ void ds_unguarded_linear_insert(u32 *e, long last)
+{
+    const u32 val = e[last];
+    long next = last - 1;
+    while (ds_less(val, e[next])) { e[last] = e[next]; last = next; --next; }
+    e[last] = val;
+}
+
+__device__ void ds_insertion_sort(u32 *e, long first, long last)
+{
+    if (first == last) return;
+    for (long i = first + 1; i != last; ++i) {
+        if (ds_less(e[i], e[first])) {
+            const u32 val = e[i];
+            for (long k = i; k > first; k--) e[k] = e[k - 1];
+            e[first] = val;
+        } else ds_unguarded_linear_insert(e, i);
+    }
+}
+
+__device__ void ds_std_sort(u32 *e, long n, long forced_depth)
+{
+    if (n <= 0) return;
+    long lg = 0;
+    for (unsigned long v = (unsigned long)n; v >>= 1;) lg++;
+    struct Part { long first, last, depth; } stack[72];                      // one pending right part per quicksort level (<= 2 lg n)
+    int sp = 0;
+    stack[sp++] = {0, n, forced_depth >= 0 ? forced_depth : 2 * lg};
+    while (sp) {
+        const Part pt = stack[--sp];
+        long first = pt.first, last = pt.last, depth = pt.depth;
+        while (last - first > 16) {
+            if (depth == 0) { ds_heap_sort(e + first, last - first); break; }
+            --depth;
+            const long mid = first + (last - first) / 2, a = first + 1, c = last - 1;
+            if (ds_less(e[a], e[mid])) {                                      // __move_median_to_first(first, first+1, mid, last-1)
+                if (ds_less(e[mid], e[c])) ds_swap(e, first, mid);
+                else if (ds_less(e[a], e[c])) ds_swap(e, first, c);
+                else ds_swap(e, first, a);
+            } else if (ds_less(e[a], e[c])) ds_swap(e, first, a);
+            else if (ds_less(e[mid], e[c])) ds_swap(e, first, c);
+            else ds_swap(e, first, mid);
+            long lo = first + 1, hi = last;                                   // __unguarded_partition(first+1, last, first)
+            for (;;) {
+                while (ds_less(e[lo], e[first])) ++lo;
+                --hi;
+                while (ds_less(e[first], e[hi])) --hi;
+                if (!(lo < hi)) break;
+                ds_swap(e, lo, hi);
+                ++lo;
+            }
+            stack[sp++] = {lo, last, depth};
+            last = lo;
+        }
+    }
+    if (n > 16) {                                                             // __final_insertion_sort
+        ds_insertion_sort(e, 0, 16);
+        for (long i = 16; i != n; ++i) ds_unguarded_linear_insert(e, i);
+    } else ds_insertion_sort(e, 0, n);
+}
+
+__global__ void k_test_list_sort(u32 *e, u64 n, long forced_depth)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) ds_std_sort(e, (long)n, forced_depth);
+}
+void launch_test_list_sort(hipStream_t s, u32 *e, u64 n, long forced_depth) { hipLaunchKernelGGL(k_test_list_sort, dim3(1), dim3(64), 0, s, e, n, forced_depth); }
+
 // ------------------------------------------------------------------ <Inexact> bytes on the device
-// Lists (nodes) whose final order needs no library sort are written by the GPU: a list of at most 16 items
-// goes through libstdc++'s std::sort as a plain insertion sort, i.e. stably, so "by decreasing block length,
-// ties in target order" is the reference's order (HTS:1368).  Longer lists (introsort, unstable) and every
-// list of a run of consecutive positions that holds tied targets (the block lengths themselves then depend
-// on the reference's push order) are left to the host, which receives just those lists.
+// Lists (nodes) are written by the GPU: a list of at most 16 items goes through libstdc++'s std::sort as a plain
+// insertion sort, i.e. stably, so "by decreasing block length, ties in target order" is the reference's order
+// (HTS:1368); a longer one is ordered by the device replica of that std::sort above.  Only the lists of a run of
+// consecutive positions that holds tied targets (the block lengths themselves then depend on the reference's push
+// order) are left to the host, which receives just those lists.
 
 // per list: does it hold a tied target; does it open a run of consecutive source positions (HTS:1212)
 __global__ __launch_bounds__(256) void k_node_class(DevParams p, const u64 *__restrict__ item_key, const u32 *__restrict__ node_start,
@@ -990,13 +1165,14 @@ __global__ __launch_bounds__(256) void k_node_size(DevParams p, int cw, const u3
                                                    const u32 *__restrict__ run_dirty, u32 n_nodes, u32 *__restrict__ size,
                                                    u32 *__restrict__ hflag, u32 *__restrict__ hcnt, DevCounters *ctr)
 {
-    __shared__ u32 s_emit[4];
+    __shared__ u32 s_emit[4], s_big[4];
     const u32 nd = blockIdx.x * 256 + threadIdx.x;
-    bool emitted = false;
+    bool emitted = false, big = false;
     if (nd < n_nodes) {
         const u32 a = node_start[nd], b = node_start[nd + 1], cnt = b - a;
         const bool dirty = run_dirty[run_excl[nd] + run_head[nd] - 1] != 0;
-        const bool host = dirty || cnt > 16;
+        const bool host = dirty || cnt >= (1u << DS_KEY_SHIFT);
+        big = cnt > 16;
         u32 sz = 0;
         if (!host) {
             u32 alive = 0;
@@ -1008,12 +1184,13 @@ __global__ __launch_bounds__(256) void k_node_size(DevParams p, int cw, const u3
         hflag[nd] = host ? 1u : 0u;
         hcnt[nd] = host ? cnt : 0u;
     }
-    const u64 bal = __ballot(emitted);
-    if ((threadIdx.x & 63) == 0) s_emit[threadIdx.x >> 6] = (u32)__popcll(bal);
+    const u64 bal = __ballot(emitted), bbig = __ballot(big);
+    if ((threadIdx.x & 63) == 0) { s_emit[threadIdx.x >> 6] = (u32)__popcll(bal); s_big[threadIdx.x >> 6] = (u32)__popcll(bbig); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const u32 t = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3];
+        const u32 t = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3], tb = s_big[0] + s_big[1] + s_big[2] + s_big[3];
         if (t) atomicAdd(&ctr->emitted_nodes, (unsigned long long)t);
+        if (tb) atomicAdd(&ctr->big_nodes, (unsigned long long)tb);
     }
 }
 
@@ -1026,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_node_write(DevParams p, int cw, const u
                                                     const u32 *__restrict__ size, const u64 *__restrict__ off, const u32 *__restrict__ hflag,
                                                     const u64 *__restrict__ hidx, const u64 *__restrict__ hoff, const u32 *__restrict__ node_tie,
                                                     u8 *__restrict__ stream, HostNode *__restrict__ hnodes, u64 *__restrict__ h_key,
-                                                    u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen)
+                                                    u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen, u32 *__restrict__ ord)
 {
     const u32 nd = blockIdx.x * 256 + threadIdx.x;
     if (nd >= n_nodes) return;
@@ -1048,6 +1225,30 @@ __global__ __launch_bounds__(256) void k_node_write(DevParams p, int cw, const u
     const u32 sc = find_contig(p, src);
     w = put_chr(w, cw, sc + 1);
     w = put_u32(w, (u32)(src - p.ctg_gstart[sc]) + 1);
+    if (b - a > 16) {                                    // std::sort's unstable regime: run the same algorithm on (length, index)
+        u32 *e = ord + a;
+        const u32 cnt = b - a;
+        for (u32 k = 0; k < cnt; k++) e[k] = ((u32)(blen[a + k] + 1) << DS_KEY_SHIFT) | k;
+        ds_std_sort(e, (long)cnt, -1);
+        for (u32 k = 0; k < cnt; k++) {
+            const u32 x = e[k];
+            if ((x >> DS_KEY_SHIFT) == 0) break;           // absorbed items (length -1) sort to the end (HTS:1376)
+            const u32 it = a + (x & ((1u << DS_KEY_SHIFT) - 1u));
+            const int L = (int)(x >> DS_KEY_SHIFT) - 1;
+            const u32 m = item_meta[it];
+            const u64 tgt = item_key[it] & 0xFFFFFFFFull;
+            const u32 tc = find_contig(p, tgt);
+            *w++ = (u8)(m & 1u);
+            w = put_chr(w, cw, tc + 1);
+            w = put_u32(w, (u32)(tgt - p.ctg_gstart[tc]) + 1);
+            *w++ = (u8)meta_o1(m);
+            if (p.d > 1) *w++ = (u8)meta_o2(m);
+            if (p.d > 2) *w++ = (u8)meta_o3(m);
+            *w++ = (u8)L; *w++ = (u8)((u32)L >> 8);
+        }
+        *w++ = 0xFF;
+        return;
+    }
     // by decreasing block length, ties in list (= target) order: pick the successor of the last one written
     int last_len = 32767 + 1;
     u32 last_k = 0;
@@ -1104,22 +1305,54 @@ __global__ __launch_bounds__(256) void k_exact_write(DevParams p, int cw, const 
                                                      const u8 *__restrict__ merge_prev, u32 n_cls, const u32 *__restrict__ size,
                                                      const u64 *__restrict__ off, u8 *__restrict__ stream)
 {
+    __shared__ u32 s_big[256];
+    __shared__ u32 s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
     const u32 c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_cls || !size[c]) return;
-    u8 *w = stream + off[c];
-    const u64 o = ent_off[c];
-    const u32 ne = cls_entries[c];
-    for (u32 k = 0; k < ne; k++) {
-        const u64 gp = ent[o + k];
-        const u32 ci = find_contig(p, gp);
-        if (k) *w++ = ent_dir[o + k];
-        w = put_chr(w, cw, ci + 1);
-        w = put_u32(w, (u32)(gp - p.ctg_gstart[ci]) + 1);
+    if (c < n_cls && size[c]) {
+        const u32 ne = cls_entries[c];
+        if (ne > COOP_MIN) {
+            s_big[atomicAdd(&s_nbig, 1u)] = c;
+        } else {
+            u8 *w = stream + off[c];
+            const u64 o = ent_off[c];
+            for (u32 k = 0; k < ne; k++) {
+                const u64 gp = ent[o + k];
+                const u32 ci = find_contig(p, gp);
+                if (k) *w++ = ent_dir[o + k];
+                w = put_chr(w, cw, ci + 1);
+                w = put_u32(w, (u32)(gp - p.ctg_gstart[ci]) + 1);
+            }
+            *w++ = 0xFF;
+            u32 e = c + 1;
+            while (e < n_cls && merge_prev[e]) e++;
+            w = put_u32(w, e - c);
+        }
     }
-    *w++ = 0xFF;
-    u32 e = c + 1;
-    while (e < n_cls && merge_prev[e]) e++;
-    w = put_u32(w, e - c);
+    __syncthreads();
+    const u32 nbig = s_nbig;
+    for (u32 b = 0; b < nbig; b++) {                             // a long record: entry k sits at a computable offset
+        const u32 cb = s_big[b];
+        u8 *w0 = stream + off[cb];
+        const u64 o = ent_off[cb];
+        const u32 ne = cls_entries[cb];
+        for (u32 k = threadIdx.x; k < ne; k += 256) {
+            const u64 gp = ent[o + k];
+            const u32 ci = find_contig(p, gp);
+            u8 *w = k ? w0 + (cw + 4) + (u64)(k - 1) * (cw + 5) : w0;
+            if (k) *w++ = ent_dir[o + k];
+            w = put_chr(w, cw, ci + 1);
+            put_u32(w, (u32)(gp - p.ctg_gstart[ci]) + 1);
+        }
+        if (threadIdx.x == 0) {
+            u8 *w = w0 + (cw + 4) + (u64)(ne - 1) * (cw + 5);
+            *w++ = 0xFF;
+            u32 e = cb + 1;
+            while (e < n_cls && merge_prev[e]) e++;
+            put_u32(w, e - cb);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ launch wrappers
@@ -1151,10 +1384,10 @@ void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node
 }
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 n_nodes, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
-                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen)
+                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen, u32 *ord)
 {
     if (n_nodes) hipLaunchKernelGGL(k_node_write, grid_for(n_nodes), dim3(256), 0, s, p, cw, item_key, item_meta, blen, node_start, n_nodes,
-                                    size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen);
+                                    size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen, ord);
 }
 
 void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr)

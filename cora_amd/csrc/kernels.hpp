@@ -53,7 +53,7 @@ struct PairRec { u32 p1, p2, meta; };
 // counters block kept on the device for one run
 struct DevCounters {
     unsigned long long n_mixed, fallback, first_singleton_key, n_pairs, n_candidates, n_dirty, format_errors;
-    unsigned long long empty_contigs, emitted_nodes, emitted_exact;
+    unsigned long long empty_contigs, emitted_nodes, emitted_exact, big_nodes;
 };
 
 
@@ -112,7 +112,9 @@ void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node
                       const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, DevCounters *ctr);
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 n_nodes, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
-                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen);
+                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen,
+                       u32 *ord /* [items] scratch of the lists above 16 items */);
+void launch_test_list_sort(hipStream_t s, u32 *e, u64 n, long forced_depth);
 
 }  // namespace cora
 

@@ -279,7 +279,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
     View<u64> packed_host;
     View<u8> stream_host;
     View<HostNode> hnodes_host;
-    u64 device_nodes = 0;
+    u64 device_nodes = 0, big_nodes = 0;
     static const u32 zero_node = 0;
     if (M >= (1ull << 32)) return fail(19, "too many directed items (%llu)", (unsigned long long)M);
     job->stats.inexact_items = M;
@@ -317,6 +317,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         RCQ(run_head.alloc(nn)); RCQ(node_tie.alloc(nn)); RCQ(run_dirty.alloc(nn)); RCQ(nsize.alloc(nn)); RCQ(hflag.alloc(nn)); RCQ(hcnt.alloc(nn));
         RCQ(run_excl.alloc(nn)); RCQ(noff.alloc(nn)); RCQ(hidx.alloc(nn)); RCQ(hoff.alloc(nn)); RCQ(tots.alloc(4));
         ZERO_COUNTERS(job, emitted_nodes, 1);
+        ZERO_COUNTERS(job, big_nodes, 1);
         launch_node_class(s, dp, kk.a, nstart.p, nn, run_head.p, node_tie.p);
         if (exclusive_scan_u32_to_u64(s, run_head.p, run_excl.p, nn, scr.p, nullptr)) return fail(100, "scan launch failed");
         HIPQ(hipMemsetAsync(run_dirty.p, 0, (size_t)nn * sizeof(u32), s));
@@ -333,9 +334,11 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         DBuf<u64> hk;
         DBuf<u32> hm;
         DBuf<int16_t> hbl;
+        DBuf<u32> ord;
+        RCQ(ord.alloc(M));
         RCQ(stream.alloc(totals[0])); RCQ(hnodes.alloc(totals[1])); RCQ(hk.alloc(totals[2])); RCQ(hm.alloc(totals[2])); RCQ(hbl.alloc(totals[2]));
         launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, nn, nsize.p, noff.p, hflag.p, hidx.p, hoff.p, node_tie.p, stream.p,
-                          hnodes.p, hk.p, hm.p, hbl.p);
+                          hnodes.p, hk.p, hm.p, hbl.p, ord.p);
         HIPQ(hipGetLastError());
         RCQ(d2h(job, job->h_stream, stream_host, (const u8 *)stream.p, totals[0]));
         RCQ(d2h(job, job->h_hnodes, hnodes_host, (const HostNode *)hnodes.p, totals[1]));
@@ -344,6 +347,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         RCQ(d2h(job, job->h_blen, ir.blen, (const int16_t *)hbl.p, totals[2]));
         RCQ(read_counters(job, h));
         device_nodes = h.emitted_nodes;
+        big_nodes = h.big_nodes;
         if (h.n_dirty) RCQ(d2h(job, job->h_packed, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
         HIPQ(hipStreamSynchronize(s));
         // list starts of the compacted host items
@@ -358,6 +362,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
     HIPQ(hipStreamSynchronize(s));
     const auto h0 = std::chrono::steady_clock::now();
     assemble_inexact(job->hg, stream_host, hnodes_host, ir, packed_host, device_nodes, job->inexact_bytes, fst, job->host_threads);
+    fst.big_nodes = big_nodes;                           // lists above 16 items, counted on the device (most never reach the host)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     host_ms += ms;
     if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] inexact host finish %.3f ms (%zu stream bytes, %zu host lists, %zu host items)\n", ms,

@@ -182,6 +182,28 @@ def workload_chr20_like(seed: int = 20, total_len: int = 64_000_000):
     return genome_with_families(seed, total_len, fams, n_runs=[(0, nlead)], name="chr20_like")
 
 
+def workload_repeat_rich(seed: int = 5, total_len: int = 100_000_000, max_copies: int = 3000):
+    """configs[4] in spirit, scaled to what ANY implementation of the reference's semantics can
+    hold: random sequence + repeat families with copy numbers from 10^2 up to ``max_copies`` at 0.5-3 % divergence
+    (pairs grow with copies^2 per position: 10^6 copies would mean 10^12 pair records per position, for the reference
+    too) + two tandem low-complexity stretches, (AT)n and (A)n, of total_len/100 bases each: exact classes with
+    ~10^6 entries, the (AT)n ones palindromic (listed twice, quirk Q2)."""
+    rs = np.random.RandomState(seed + 7)
+    fams = []
+    copies = 100
+    while copies <= max_copies:
+        fams.append((int(rs.choice([150, 300, 600])), copies, float(rs.choice([0.005, 0.01, 0.02, 0.03])), 3))
+        copies *= 3
+    fams += [(1200, 40, 0.01, 2), (6000, 10, 0.005, 0)]
+    contig = genome_with_families(seed, total_len, fams, name="repeat_rich")
+    g = contig[0][1]
+    run = total_len // 100
+    a0, a1 = total_len // 3, 2 * total_len // 3
+    g[a0:a0 + run] = np.resize(np.frombuffer(b"AT", dtype=np.uint8), run)
+    g[a1:a1 + run] = ord("A")
+    return contig
+
+
 def ensure_dir(p: str) -> str:
     os.makedirs(p, exist_ok=True)
     return p

@@ -203,6 +203,11 @@ int cora_hip_radix_sort(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val,
 
 /* Host-buffer convenience wrappers for tests: copy in, run the kernels, copy out. */
 int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val, uint64_t n, int bit_lo, int bit_hi);
+/* The device replica of libstdc++'s std::sort with the reference's comparator sort_by_decreasing_blockLen (HTS:1110-1113,
+ * used at HTS:1368): sorts n u32 elements (block length + 1) << 25 | index, comparing the top 7 bits only, with ONE GPU
+ * thread, as the table writer does for every list above 16 items.  forced_depth >= 0 replaces introsort's depth limit
+ * 2 lg n (0 = heapsort at once), so that tests reach the heapsort branch. */
+int cora_hip_test_list_sort(uint32_t *elems, uint64_t n, int forced_depth);
 /* 2-bit pack + validity of the reference image of a job (after set_reference):
  * fills packed[ceil(G/32)] (base i of the padded global coordinate at bits
  * 62-2*(i%32) of word i/32), bad[ceil(G/32)] (bit 31-(i%32)), and contig_start[n_contigs]. */

@@ -119,6 +119,21 @@ def test_low_complexity_and_iupac(K, d, tmp_path):
         assert inx == helpers.read(oinx), "Inexact differs (sharded=%s)" % sharded
 
 
+def test_long_classes_that_merge_into_blocks(tmp_path):
+    """300 identical copies of a 400-base unit (every 3rd reverse-complemented): classes of 300 entries, consecutive
+    ones merging into blocks -- the entry lists, the merge test and the record bytes of such classes are produced by
+    whole workgroups instead of single threads (COOP_MIN in kernels.hip)."""
+    contig = synth.genome_with_families(9, 400_000, [(400, 300, 0.0, 3), (130, 200, 0.0, 0)], name="dup")
+    fa = str(tmp_path / "dup.fa")
+    synth.write_fasta(fa, contig, 60)
+    oex, oinx = helpers.run_oracle(fa, 50, 2, helpers.split_path("phys", 2), helpers.split_path("par", 3), str(tmp_path / "o"))
+    assert os.path.getsize(oex) > 300 * 5 * 2
+    for sharded in (False, True):
+        ex, en, inx, inn = _build(fa, 50, 2, 2, 3, sharded=sharded)
+        assert ex == helpers.read(oex), "Exact differs (sharded=%s)" % sharded
+        assert inx == helpers.read(oinx), "Inexact differs (sharded=%s)" % sharded
+
+
 def test_sharded_stages_at_full_size_match_reference_hash():
     """The multi-GPU stage functions on bench.py's workload (one rank): same sha256 as the real reference's tables."""
     import hashlib
