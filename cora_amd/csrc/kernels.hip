@@ -542,6 +542,17 @@ __global__ __launch_bounds__(256) void k_bitmap_emit(const u32 *__restrict__ bit
 // Classes, records and lists are handled one per thread; one longer than this (Mbp of tandem repeats make classes of
 // 10^6 entries) is queued in LDS and then shared by the whole workgroup.
 constexpr u32 COOP_MIN = 128;
+// ... and one longer than this is noted in a short list (DevCounters::Huge) and spread over a whole grid by a follow-up
+// kernel; if the list is full the workgroup path takes it.
+constexpr u32 HUGE_MIN = 1u << 16;
+constexpr u32 HUGE_GRID = 1024;
+__device__ __forceinline__ bool note_huge(DevCounters::Huge *h, u32 id)
+{
+    const u32 at = atomicAdd(&h->n, 1u);
+    if (at >= 31u) return false;
+    h->id[at] = id;
+    return true;
+}
 
 // cls[k] = rep<<32 | class index, sorted by rep.  flags: bit0 palindrome, bit1 flip, bit2 rep strand, bit3 leading.
 __global__ __launch_bounds__(256) void k_class_info(const u64 *__restrict__ rec, const u32 *__restrict__ class_start,
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(256) void k_class_info(const u64 *__restrict__ rec,
 __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
                                                        const u32 *__restrict__ class_start, const u64 *__restrict__ cls, u32 n_cls,
                                                        const u32 *__restrict__ cls_flags, const u64 *__restrict__ ent_off,
-                                                       u32 *__restrict__ ent, u8 *__restrict__ ent_dir)
+                                                       u32 *__restrict__ ent, u8 *__restrict__ ent_dir, DevCounters *ctr)
 {
     __shared__ u32 s_big[256];
     __shared__ u32 s_nbig;
@@ -578,7 +589,9 @@ __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ r
     if (k < n_cls) {
         const u32 c = (u32)cls[k];
         const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[k];
-        if (m > COOP_MIN) {
+        if (m > HUGE_MIN && note_huge(&ctr->huge_entries, k)) {
+            // left to k_class_entries_huge
+        } else if (m > COOP_MIN) {
             s_big[atomicAdd(&s_nbig, 1u)] = k;                  // a long class (low-complexity sequence): the whole block shares it
         } else {
             u64 o = ent_off[k];
@@ -599,6 +612,27 @@ __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ r
         const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[kb];
         const u64 o = ent_off[kb];
         for (u32 j = threadIdx.x; j < m; j += 256) {
+            const u32 g = gpos[st + j];
+            if (fl & 1u) {
+                ent[o + 2ull * j] = g; ent_dir[o + 2ull * j] = 0; ent[o + 2ull * j + 1] = g; ent_dir[o + 2ull * j + 1] = 1;
+            } else {
+                ent[o + j] = g; ent_dir[o + j] = (u8)(((u32)rec[st + j] & 1u) ^ ((fl >> 1) & 1u));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_class_entries_huge(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
+                                                            const u32 *__restrict__ class_start, const u64 *__restrict__ cls,
+                                                            const u32 *__restrict__ cls_flags, const u64 *__restrict__ ent_off,
+                                                            u32 *__restrict__ ent, u8 *__restrict__ ent_dir, const DevCounters *ctr)
+{
+    const u32 nh = ctr->huge_entries.n < 31u ? ctr->huge_entries.n : 31u;
+    for (u32 h = 0; h < nh; h++) {
+        const u32 kb = ctr->huge_entries.id[h], c = (u32)cls[kb];
+        const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[kb];
+        const u64 o = ent_off[kb];
+        for (u32 j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
             const u32 g = gpos[st + j];
             if (fl & 1u) {
                 ent[o + 2ull * j] = g; ent_dir[o + 2ull * j] = 0; ent[o + 2ull * j + 1] = g; ent_dir[o + 2ull * j + 1] = 1;
@@ -1303,7 +1337,7 @@ __global__ __launch_bounds__(256) void k_exact_size(int cw, const u32 *__restric
 __global__ __launch_bounds__(256) void k_exact_write(DevParams p, int cw, const u32 *__restrict__ cls_entries, const u64 *__restrict__ ent_off,
                                                      const u32 *__restrict__ ent, const u8 *__restrict__ ent_dir,
                                                      const u8 *__restrict__ merge_prev, u32 n_cls, const u32 *__restrict__ size,
-                                                     const u64 *__restrict__ off, u8 *__restrict__ stream)
+                                                     const u64 *__restrict__ off, u8 *__restrict__ stream, DevCounters *ctr)
 {
     __shared__ u32 s_big[256];
     __shared__ u32 s_nbig;
@@ -1312,7 +1346,9 @@ __global__ __launch_bounds__(256) void k_exact_write(DevParams p, int cw, const 
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     if (c < n_cls && size[c]) {
         const u32 ne = cls_entries[c];
-        if (ne > COOP_MIN) {
+        if (ne > HUGE_MIN && note_huge(&ctr->huge_write, c)) {
+            // left to k_exact_write_huge
+        } else if (ne > COOP_MIN) {
             s_big[atomicAdd(&s_nbig, 1u)] = c;
         } else {
             u8 *w = stream + off[c];
@@ -1355,6 +1391,35 @@ __global__ __launch_bounds__(256) void k_exact_write(DevParams p, int cw, const 
     }
 }
 
+__global__ __launch_bounds__(256) void k_exact_write_huge(DevParams p, int cw, const u32 *__restrict__ cls_entries, const u64 *__restrict__ ent_off,
+                                                          const u32 *__restrict__ ent, const u8 *__restrict__ ent_dir,
+                                                          const u8 *__restrict__ merge_prev, u32 n_cls, const u64 *__restrict__ off,
+                                                          u8 *__restrict__ stream, const DevCounters *ctr)
+{
+    const u32 nh = ctr->huge_write.n < 31u ? ctr->huge_write.n : 31u;
+    for (u32 h = 0; h < nh; h++) {
+        const u32 cb = ctr->huge_write.id[h];
+        u8 *w0 = stream + off[cb];
+        const u64 o = ent_off[cb];
+        const u32 ne = cls_entries[cb];
+        for (u32 k = blockIdx.x * 256 + threadIdx.x; k < ne; k += gridDim.x * 256) {
+            const u64 gp = ent[o + k];
+            const u32 ci = find_contig(p, gp);
+            u8 *w = k ? w0 + (cw + 4) + (u64)(k - 1) * (cw + 5) : w0;
+            if (k) *w++ = ent_dir[o + k];
+            w = put_chr(w, cw, ci + 1);
+            put_u32(w, (u32)(gp - p.ctg_gstart[ci]) + 1);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            u8 *w = w0 + (cw + 4) + (u64)(ne - 1) * (cw + 5);
+            *w++ = 0xFF;
+            u32 e = cb + 1;
+            while (e < n_cls && merge_prev[e]) e++;
+            put_u32(w, e - cb);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ launch wrappers
 static inline dim3 grid_for(u64 n) { return dim3((unsigned)((n + 255) / 256)); }
 
@@ -1363,10 +1428,14 @@ void launch_exact_size(hipStream_t s, int cw, const u32 *cls_entries, const u8 *
     if (n_cls) hipLaunchKernelGGL(k_exact_size, grid_for(n_cls), dim3(256), 0, s, cw, cls_entries, merge_prev, n_cls, size, ctr);
 }
 void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cls_entries, const u64 *ent_off, const u32 *ent, const u8 *ent_dir,
-                        const u8 *merge_prev, u32 n_cls, const u32 *size, const u64 *off, u8 *stream)
+                        const u8 *merge_prev, u32 n_cls, const u32 *size, const u64 *off, u8 *stream, DevCounters *ctr)
 {
-    if (n_cls) hipLaunchKernelGGL(k_exact_write, grid_for(n_cls), dim3(256), 0, s, p, cw, cls_entries, ent_off, ent, ent_dir, merge_prev, n_cls,
-                                  size, off, stream);
+    if (!n_cls) return;
+    (void)hipMemsetAsync(&ctr->huge_write, 0, sizeof(DevCounters::Huge), s);
+    hipLaunchKernelGGL(k_exact_write, grid_for(n_cls), dim3(256), 0, s, p, cw, cls_entries, ent_off, ent, ent_dir, merge_prev, n_cls,
+                       size, off, stream, ctr);
+    hipLaunchKernelGGL(k_exact_write_huge, dim3(HUGE_GRID), dim3(256), 0, s, p, cw, cls_entries, ent_off, ent, ent_dir, merge_prev, n_cls,
+                       off, stream, ctr);
 }
 void launch_node_class(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *node_start, u32 n_nodes, u32 *run_head, u32 *node_tie)
 {
@@ -1473,9 +1542,12 @@ void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, co
     if (n_cls) hipLaunchKernelGGL(k_class_info, grid_for(n_cls), dim3(256), 0, s, rec, class_start, cls, n_cls, ctr, cls_flags, cls_entries);
 }
 void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, const u64 *cls, u32 n_cls,
-                          const u32 *cls_flags, const u64 *ent_off, u32 *ent, u8 *ent_dir)
+                          const u32 *cls_flags, const u64 *ent_off, u32 *ent, u8 *ent_dir, DevCounters *ctr)
 {
-    if (n_cls) hipLaunchKernelGGL(k_class_entries, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, cls, n_cls, cls_flags, ent_off, ent, ent_dir);
+    if (!n_cls) return;
+    (void)hipMemsetAsync(&ctr->huge_entries, 0, sizeof(DevCounters::Huge), s);
+    hipLaunchKernelGGL(k_class_entries, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, cls, n_cls, cls_flags, ent_off, ent, ent_dir, ctr);
+    hipLaunchKernelGGL(k_class_entries_huge, dim3(HUGE_GRID), dim3(256), 0, s, rec, gpos, class_start, cls, cls_flags, ent_off, ent, ent_dir, ctr);
 }
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off, const u32 *ent,
                         const u8 *ent_dir, u8 *merge_prev)

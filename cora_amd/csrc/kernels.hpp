@@ -54,6 +54,7 @@ struct PairRec { u32 p1, p2, meta; };
 struct DevCounters {
     unsigned long long n_mixed, fallback, first_singleton_key, n_pairs, n_candidates, n_dirty, format_errors;
     unsigned long long empty_contigs, emitted_nodes, emitted_exact, big_nodes;
+    struct Huge { u32 n; u32 id[31]; } huge_entries, huge_write;   // classes too long for one workgroup (kernels.hip: HUGE_MIN)
 };
 
 
@@ -84,7 +85,7 @@ void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *
 void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,
                        u32 *cls_flags, u32 *cls_entries);
 void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, const u64 *cls, u32 n_cls,
-                          const u32 *cls_flags, const u64 *ent_off, u32 *ent /* gpos */, u8 *ent_dir);
+                          const u32 *cls_flags, const u64 *ent_off, u32 *ent /* gpos */, u8 *ent_dir, DevCounters *ctr);
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off,
                         const u32 *ent, const u8 *ent_dir, u8 *merge_prev);
 void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out);
@@ -105,7 +106,7 @@ void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const 
 
 void launch_exact_size(hipStream_t s, int cw, const u32 *cls_entries, const u8 *merge_prev, u32 n_cls, u32 *size, DevCounters *ctr);
 void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cls_entries, const u64 *ent_off, const u32 *ent, const u8 *ent_dir,
-                        const u8 *merge_prev, u32 n_cls, const u32 *size, const u64 *off, u8 *stream);
+                        const u8 *merge_prev, u32 n_cls, const u32 *size, const u64 *off, u8 *stream, DevCounters *ctr);
 void launch_node_class(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *node_start, u32 n_nodes, u32 *run_head, u32 *node_tie);
 void launch_run_dirty(hipStream_t s, const u32 *node_tie, const u64 *run_excl, const u32 *run_head, u32 n_nodes, u32 *run_dirty);
 void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node_start, const int16_t *blen, const u64 *run_excl,

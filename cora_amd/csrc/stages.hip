@@ -136,7 +136,7 @@ int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p)
     HIPQ(hipMemcpyAsync(&p.NE, tot.p, sizeof p.NE, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
     RCQ(p.ent.alloc(p.NE)); RCQ(p.edir.alloc(p.NE));
-    launch_class_entries(s, x.rec_s, x.gp_s, x.class_start.p, x.cls.p, (u32)x.NNS, cf.p, eoff.p, p.ent.p, p.edir.p);
+    launch_class_entries(s, x.rec_s, x.gp_s, x.class_start.p, x.cls.p, (u32)x.NNS, cf.p, eoff.p, p.ent.p, p.edir.p, job->ctr.p);
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
     return 0;
@@ -177,7 +177,7 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
         HIPQ(hipStreamSynchronize(s));
         DBuf<u8> stream;
         RCQ(stream.alloc(total));
-        launch_exact_write(s, dp, cw, ce_s.p, eoff_s.p, p.ent.p, p.edir.p, mp.p, (u32)n, csize.p, coff.p, stream.p);
+        launch_exact_write(s, dp, cw, ce_s.p, eoff_s.p, p.ent.p, p.edir.p, mp.p, (u32)n, csize.p, coff.p, stream.p, job->ctr.p);
         View<u8> bytes;
         RCQ(d2h(job, job->h_stream, bytes, (const u8 *)stream.p, total));
         RCQ(read_counters(job, h));

@@ -134,6 +134,26 @@ def test_long_classes_that_merge_into_blocks(tmp_path):
         assert inx == helpers.read(oinx), "Inexact differs (sharded=%s)" % sharded
 
 
+def _tandem_reference(path):
+    rs = np.random.RandomState(12)
+    seq = np.concatenate([synth.random_seq(rs, 30000), synth.seq_from_str("AT" * 70000), synth.random_seq(rs, 20000),
+                          synth.seq_from_str("A" * 70000), synth.random_seq(rs, 10000)])
+    synth.write_fasta(path, [("tandem", seq)], 60)
+
+
+def test_huge_classes_spread_over_the_grid(tmp_path):
+    """140 kbp of (AT)n and 70 kbp of (A)n: two palindromic classes of ~140 000 entries and one of ~70 000, above
+    HUGE_MIN (kernels.hip), so their entry lists and record bytes are written by the follow-up grid-wide kernels."""
+    fa = str(tmp_path / "tandem.fa")
+    _tandem_reference(fa)
+    oex, oinx = helpers.run_oracle(fa, 50, 2, helpers.split_path("phys", 1), helpers.split_path("par", 1), str(tmp_path / "o"))
+    assert os.path.getsize(oex) > 2 * 140000 * 5
+    for sharded in (False, True):
+        ex, en, inx, inn = _build(fa, 50, 2, 1, 1, sharded=sharded)
+        assert ex == helpers.read(oex), "Exact differs (sharded=%s)" % sharded
+        assert inx == helpers.read(oinx), "Inexact differs (sharded=%s)" % sharded
+
+
 def test_sharded_stages_at_full_size_match_reference_hash():
     """The multi-GPU stage functions on bench.py's workload (one rank): same sha256 as the real reference's tables."""
     import hashlib
