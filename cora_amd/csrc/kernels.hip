@@ -276,21 +276,34 @@ __global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__r
     if ((threadIdx.x & 63) == 0) head_mask[i >> 6] = bal;
 }
 
-// One thread per listed position: the lowest listed position of an equal-hash run sorts that run by
-// canonical key (stable, so equal keys stay in position order).  Runs longer than 64 records set the
-// fallback flag: the caller then redoes the stage with the full-key sort.
+// One thread per listed position.  The run of equal truncated hashes around it is found by binary search (the records
+// are sorted on those bits); the first thread to claim the run's start repairs it: a run of at most 64 records is
+// sorted by canonical key in registers (stable, so equal keys stay in position order), a longer one -- a K-mer with
+// many copies that collided with another K-mer -- is listed for k_mixed_fix_long.
 __global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__restrict__ pk, u64 *__restrict__ rec,
                                                   u32 *__restrict__ gpos, u64 n, int hb, const u32 *__restrict__ mixed_list,
-                                                  u32 n_mixed, u64 *head_mask, DevCounters *ctr)
+                                                  u32 n_mixed, u64 *head_mask, u32 *__restrict__ claim,
+                                                  u64 *__restrict__ long_runs, u32 long_cap, DevCounters *ctr)
 {
     const u32 t = blockIdx.x * 64 + threadIdx.x;
     if (t >= n_mixed) return;
     const u64 i = mixed_list[t];
-    const u64 tr = rec[i] >> (64 - hb);
-    u64 s = i, e = i + 1;
-    while (s > 0 && (rec[s - 1] >> (64 - hb)) == tr) { s--; if (i - s > 64) { ctr->fallback = 1; return; } }
-    while (e < n && (rec[e] >> (64 - hb)) == tr) { e++; if (e - s > 64) { ctr->fallback = 1; return; } }
-    for (u32 k = 0; k < n_mixed; k++) { const u64 o = mixed_list[k]; if (o >= s && o < i) return; }   // not the run's first
+    const int sh = 64 - hb;
+    const u64 tr = rec[i] >> sh;
+    u64 lo = 0, hi = i;                                    // first record of the run: lowest index whose bits are >= tr
+    while (lo < hi) { const u64 m = (lo + hi) >> 1; if ((rec[m] >> sh) < tr) lo = m + 1; else hi = m; }
+    const u64 s = lo;
+    lo = i + 1; hi = n;                                    // one past its last record
+    while (lo < hi) { const u64 m = (lo + hi) >> 1; if ((rec[m] >> sh) <= tr) lo = m + 1; else hi = m; }
+    const u64 e = lo;
+    const u32 bit = 1u << (s & 31);
+    if (atomicOr(&claim[s >> 5], bit) & bit) return;       // another listed position of this run got here first
+    if (e - s > 64) {
+        const unsigned long long at = atomicAdd(&ctr->n_long, 1ull);
+        if (at < long_cap) { long_runs[2 * at] = s; long_runs[2 * at + 1] = e; }
+        else ctr->fallback = 1;
+        return;
+    }
     const int L = (int)(e - s);
     u64 r_[64], kh[64], kl[64];
     u32 g_[64];
@@ -304,9 +317,77 @@ __global__ __launch_bounds__(64) void k_mixed_fix(DevParams p, const u64 *__rest
     }
     for (int k = 0; k < L; k++) {                         // the run in key order, and its class heads
         rec[s + k] = r_[k]; gpos[s + k] = g_[k];
-        const u64 bit = 1ull << ((s + k) & 63);           // other runs may share the word
-        if (k == 0 || kh[k] != kh[k - 1] || kl[k] != kl[k - 1]) atomicOr((unsigned long long *)&head_mask[(s + k) >> 6], bit);
-        else atomicAnd((unsigned long long *)&head_mask[(s + k) >> 6], ~bit);
+        const u64 hbit = 1ull << ((s + k) & 63);          // other runs may share the word
+        if (k == 0 || kh[k] != kh[k - 1] || kl[k] != kl[k - 1]) atomicOr((unsigned long long *)&head_mask[(s + k) >> 6], hbit);
+        else atomicAnd((unsigned long long *)&head_mask[(s + k) >> 6], ~hbit);
+    }
+}
+
+// One workgroup per long run: it holds few distinct K-mers (one with many copies plus whatever collided with it), so
+// the run is copied aside and rebuilt key by key in ascending key order, each key's records compacted in their
+// original (= position) order.  A run with more than MIXED_MAX_KEYS distinct keys (only when tests shorten the hash)
+// is put back as it was and the fallback flag is set.
+constexpr int MIXED_MAX_KEYS = 8;
+__global__ __launch_bounds__(256) void k_mixed_fix_long(DevParams p, const u64 *__restrict__ pk, u64 *__restrict__ rec, u32 *__restrict__ gpos,
+                                                        u64 *__restrict__ rec_copy, u32 *__restrict__ gpos_copy,
+                                                        const u64 *__restrict__ long_runs, u64 *head_mask, DevCounters *ctr)
+{
+    __shared__ u64 s_h[256], s_l[256];
+    __shared__ u32 s_cnt[4];
+    const u64 s = long_runs[2 * blockIdx.x], e = long_runs[2 * blockIdx.x + 1];
+    const u64 L = e - s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (u64 k = tid; k < L; k += 256) { rec_copy[s + k] = rec[s + k]; gpos_copy[s + k] = gpos[s + k]; }
+    __syncthreads();
+    u64 last_h = 0, last_l = 0, out = 0;
+    bool have_last = false, gave_up = false;
+    for (int pass = 0; out < L; pass++) {
+        if (pass == MIXED_MAX_KEYS) { gave_up = true; break; }
+        u64 mh = ~0ull, ml = ~0ull;                        // smallest key above the last one (all ones is no canonical key: T^K's is A^K)
+        bool any = false;
+        for (u64 k = tid; k < L; k += 256) {
+            u64 kh, kl;
+            canonical_at(p, pk, gpos_copy[s + k], kh, kl);
+            const bool above = !have_last || kh > last_h || (kh == last_h && kl > last_l);
+            if (above && (!any || kh < mh || (kh == mh && kl < ml))) { mh = kh; ml = kl; any = true; }
+        }
+        s_h[tid] = mh; s_l[tid] = ml;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const u64 oh = s_h[tid + o], ol = s_l[tid + o];
+                if (oh < s_h[tid] || (oh == s_h[tid] && ol < s_l[tid])) { s_h[tid] = oh; s_l[tid] = ol; }
+            }
+            __syncthreads();
+        }
+        mh = s_h[0]; ml = s_l[0];                          // some record is above `last` while out < L, so this is a real key
+        __syncthreads();
+        const u64 group_start = out;
+        for (u64 base = 0; base < L; base += 256) {
+            const u64 k = base + tid;
+            bool f = false;
+            if (k < L) { u64 kh, kl; canonical_at(p, pk, gpos_copy[s + k], kh, kl); f = (kh == mh && kl == ml); }
+            const u64 bal = __ballot(f);
+            if (lane == 0) s_cnt[wv] = (u32)__popcll(bal);
+            __syncthreads();
+            u32 pre = 0;
+            for (int w = 0; w < wv; w++) pre += s_cnt[w];
+            const u32 total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            if (f) {
+                const u64 at = out + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+                rec[s + at] = rec_copy[s + k]; gpos[s + at] = gpos_copy[s + k];
+                const u64 hbit = 1ull << ((s + at) & 63);
+                if (at == group_start) atomicOr((unsigned long long *)&head_mask[(s + at) >> 6], hbit);
+                else atomicAnd((unsigned long long *)&head_mask[(s + at) >> 6], ~hbit);
+            }
+            out += total;
+            __syncthreads();
+        }
+        last_h = mh; last_l = ml; have_last = true;
+    }
+    if (gave_up) {
+        for (u64 k = tid; k < L; k += 256) { rec[s + k] = rec_copy[s + k]; gpos[s + k] = gpos_copy[s + k]; }
+        if (tid == 0) ctr->fallback = 1;
     }
 }
 
@@ -1486,9 +1567,15 @@ void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const 
     if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_mask, mixed_list, mixed_cap, ctr);
 }
 void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u64 *head_mask, const u32 *mixed_list,
-                      u32 n_mixed, DevCounters *ctr)
+                      u32 n_mixed, u32 *claim, u64 *long_runs, u32 long_cap, DevCounters *ctr)
 {
-    if (n_mixed) hipLaunchKernelGGL(k_mixed_fix, dim3((n_mixed + 63) / 64), dim3(64), 0, s, p, pk, rec, gpos, n, hb, mixed_list, n_mixed, head_mask, ctr);
+    if (n_mixed) hipLaunchKernelGGL(k_mixed_fix, dim3((n_mixed + 63) / 64), dim3(64), 0, s, p, pk, rec, gpos, n, hb, mixed_list, n_mixed, head_mask,
+                                    claim, long_runs, long_cap, ctr);
+}
+void launch_mixed_fix_long(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 *rec_copy, u32 *gpos_copy,
+                           const u64 *long_runs, u32 n_long, u64 *head_mask, DevCounters *ctr)
+{
+    if (n_long) hipLaunchKernelGGL(k_mixed_fix_long, dim3(n_long), dim3(256), 0, s, p, pk, rec, gpos, rec_copy, gpos_copy, long_runs, head_mask, ctr);
 }
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos, u64 n,
                             u64 *head_mask, u64 *rec)

@@ -53,7 +53,7 @@ struct PairRec { u32 p1, p2, meta; };
 // counters block kept on the device for one run
 struct DevCounters {
     unsigned long long n_mixed, fallback, first_singleton_key, n_pairs, n_candidates, n_dirty, format_errors;
-    unsigned long long empty_contigs, emitted_nodes, emitted_exact, big_nodes;
+    unsigned long long empty_contigs, emitted_nodes, emitted_exact, big_nodes, n_long;
     struct Huge { u32 n; u32 id[31]; } huge_entries, huge_write;   // classes too long for one workgroup (kernels.hip: HUGE_MIN)
 };
 
@@ -68,7 +68,10 @@ void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCo
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
                         u64 *head_mask /* [ceil(n/256)*4], bit l of word w = record 64w+l */, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr);
 void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u64 *head_mask,
-                      const u32 *mixed_list, u32 n_mixed, DevCounters *ctr);
+                      const u32 *mixed_list, u32 n_mixed, u32 *claim /* zeroed bitmap over the records */,
+                      u64 *long_runs /* [2 * long_cap] (start, end) of runs above 64 records */, u32 long_cap, DevCounters *ctr);
+void launch_mixed_fix_long(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 *rec_copy, u32 *gpos_copy,
+                           const u64 *long_runs, u32 n_long, u64 *head_mask, DevCounters *ctr);
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
                             u64 n, u64 *head_mask, u64 *rec);
 void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,

@@ -47,11 +47,12 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     if (N >= (1ull << 32) - 1) return fail(19, "too many K-mers for 32-bit indices");
     DBuf<u64> head_flag;                        // one bit per record: opens a class
     DBuf<u32> mixed_list;
-    const u32 mixed_cap = 4096;
+    const u32 mixed_cap = 65536, long_cap = 4096;
     RCQ(x.trec.alloc(N)); RCQ(x.tgp.alloc(N)); RCQ(head_flag.alloc(((N + 255) / 256) * 4)); RCQ(mixed_list.alloc(mixed_cap));
     // Equal canonical keys have equal hashes: sort 12-byte (hash, position) records on the top hb hash bits
     // (6-7 passes) instead of 20-byte full keys on 2K bits (13 passes); collisions are found and repaired below.
-    const int hb = job->hash_bits ? job->hash_bits : (N <= (1ull << 27) ? 48 : 56);
+    // About N^2 / 2^(hb+1) pairs of different K-mers collide: a few thousand with 40 bits up to 2^27 records, with 48 up to 2^32.
+    const int hb = job->hash_bits ? job->hash_bits : (N <= (1ull << 27) ? 40 : 48);
     SortArrays keys, tmp;
     keys.a = x.rec.p; keys.c = x.gp.p; tmp.a = x.trec.p; tmp.c = x.tgp.p;
     if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
@@ -63,10 +64,21 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     st.hash_mixed_runs += h.n_mixed;
     if (h.n_mixed > mixed_cap) fallback = true;
     else if (h.n_mixed) {
-        // the repair re-orders each such run by key and rewrites its class heads; a run it cannot hold sets the fallback flag
-        launch_mixed_fix(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, (u32)h.n_mixed, job->ctr.p);
+        // the repair re-orders each such run by key and rewrites its class heads; short runs in registers, long ones
+        // (a many-copy K-mer that collided) by a workgroup each, using the sort's spare buffers as the copy
+        DBuf<u32> claim;
+        DBuf<u64> long_runs;
+        RCQ(claim.alloc(N / 32 + 1)); RCQ(long_runs.alloc(2 * (size_t)long_cap));
+        HIPQ(hipMemsetAsync(claim.p, 0, (N / 32 + 1) * sizeof(u32), s));
+        ZERO_COUNTERS(job, n_long, 1);
+        launch_mixed_fix(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, (u32)h.n_mixed, claim.p, long_runs.p, long_cap, job->ctr.p);
         RCQ(read_counters(job, h));
         if (h.fallback) fallback = true;
+        else if (h.n_long) {
+            launch_mixed_fix_long(s, dp, job->pk.p, keys.a, keys.c, tmp.a, tmp.c, long_runs.p, (u32)h.n_long, head_flag.p, job->ctr.p);
+            RCQ(read_counters(job, h));
+            if (h.fallback) fallback = true;
+        }
     }
     x.rec_s = keys.a; x.gp_s = keys.c;
     if (fallback) {                 // a long run of colliding keys: redo on the full 128-bit keys (always exact).

@@ -154,6 +154,24 @@ def test_huge_classes_spread_over_the_grid(tmp_path):
         assert inx == helpers.read(oinx), "Inexact differs (sharded=%s)" % sharded
 
 
+def test_long_equal_hash_run_is_repaired_in_place(tmp_path, monkeypatch):
+    """With a 16-bit hash every one of the 65 536 hash values is shared by about two of the 60 000 distinct K-mers of
+    this reference, so the three classes of 70 000+ members collide with others for certain: equal-hash runs far
+    above 64 records with a handful of distinct keys, rebuilt by k_mixed_fix_long without the full-key sort."""
+    fa = str(tmp_path / "tandem.fa")
+    _tandem_reference(fa)
+    oex, oinx = helpers.run_oracle(fa, 50, 2, helpers.split_path("phys", 1), helpers.split_path("par", 1), str(tmp_path / "o"))
+    monkeypatch.setenv("CORA_HASH_BITS", "16")
+    job = hip.Job(50, 2, helpers.split_path("phys", 1), helpers.split_path("par", 1))
+    job.set_reference_file(fa)
+    job.run()
+    ex, en, inx, inn = job.tables()
+    st = job.stats()
+    job.close()
+    assert ex == helpers.read(oex) and inx == helpers.read(oinx)
+    assert st["hash_mixed_runs"] > 1000 and st["full_key_fallback"] == 0
+
+
 def test_sharded_stages_at_full_size_match_reference_hash():
     """The multi-GPU stage functions on bench.py's workload (one rank): same sha256 as the real reference's tables."""
     import hashlib
