@@ -27,7 +27,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "tables::").split("(")[0]
         a = acc.setdefault(name, [set(), 0.0])
         a[0].add(r["Dispatch_Id"])
         a[1] += float(r["Counter_Value"])
