@@ -304,6 +304,34 @@ __global__ void k_hub_replay(ExactView x, Contigs c, u32 *__restrict__ hom_hub)
     }
 }
 
+// RetrieveOffsetAndDirInfo (MI:6618-6674) for a batch of positions, one thread each: the hub names the class, then the
+// representative's range and the members' ranges are tried in list order, in the reference's unsigned arithmetic.
+// result: class index (1-based, 0 = no class), block offset, direction from the position to the representative.
+__global__ __launch_bounds__(256) void k_lookup_equiv(ExactView x, Contigs c, const u32 *__restrict__ equiv_hub,
+                                                      const u32 *__restrict__ q_chr, const u32 *__restrict__ q_pos, u64 n,
+                                                      u32 *__restrict__ r_idx, int16_t *__restrict__ r_off, u8 *__restrict__ r_dir, LoadCounters *ctr)
+{
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u32 chr = q_chr[q], pos = q_pos[q];
+    u32 idx = 0; int16_t off = 0; u8 dir = 0;
+    u64 g;
+    if (hub_index(c, chr, pos, g)) idx = equiv_hub[g];               // a key the maps cannot hold is "not found" (MI:6621-6630)
+    if (idx) {
+        const u32 i = idx - 1, bl = x.block[i], rp = x.pos[i];
+        bool found = false;
+        if (chr == x.chr[i] && pos >= rp && pos < rp + bl) { off = (int16_t)(pos - rp); found = true; }
+        for (u64 k = x.off[i]; !found && k < x.off[i + 1]; k++) {
+            if (chr != x.i_chr[k]) continue;
+            const u32 hp = x.i_pos[k];
+            if (x.i_dir[k] == 0) { if (pos >= hp && pos < hp + bl) { off = (int16_t)(pos - hp); found = true; } }
+            else if (pos <= hp && pos > hp - bl) { dir = 1; off = (int16_t)(hp - pos); found = true; }
+        }
+        if (!found) { atomicAdd(&ctr->err_range, 1u); idx = 0xFFFFFFFFu; }   // the reference asserts here (MI:6673)
+    }
+    r_idx[q] = idx; r_off[q] = off; r_dir[q] = dir;
+}
+
 u32 grid_for(u64 n, u32 per) { return (u32)((n + per - 1) / per ? (n + per - 1) / per : 1); }
 
 }  // namespace
@@ -577,6 +605,43 @@ int cora_hip_tables_export(const cora_hip_tables *t, int which, void *dst_host, 
         HIPQ(hipSetDevice(g_device));
         HIPQ(hipMemcpy(dst_host, p, n * eb, hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+int cora_hip_tables_lookup_equiv(const cora_hip_tables *t, const uint32_t *chr, const uint32_t *pos, uint64_t n, int on_device,
+                                 uint32_t *class_index, int16_t *block_offset, uint8_t *dir)
+{
+    g_err.clear();
+    if (!t) return fail(1, "cora_hip_tables_lookup_equiv: NULL tables");
+    if (!n) return 0;
+    if (!chr || !pos || !class_index || !block_offset || !dir) return fail(1, "cora_hip_tables_lookup_equiv: NULL array");
+    HIPQ(hipSetDevice(g_device));
+    PoolScope no_pool(nullptr);
+    hipStream_t s = t->stream;
+    DBuf<u32> dc, dp, di; DBuf<int16_t> dof; DBuf<u8> dd; DBuf<LoadCounters> ctr;
+    const u32 *qc = chr, *qp = pos;
+    u32 *ri = class_index; int16_t *ro = block_offset; u8 *rd = dir;
+    if (!on_device) {
+        RCQ(dc.alloc(n)); RCQ(dp.alloc(n)); RCQ(di.alloc(n)); RCQ(dof.alloc(n)); RCQ(dd.alloc(n));
+        HIPQ(hipMemcpyAsync(dc.p, chr, n * 4, hipMemcpyHostToDevice, s));
+        HIPQ(hipMemcpyAsync(dp.p, pos, n * 4, hipMemcpyHostToDevice, s));
+        qc = dc.p; qp = dp.p; ri = di.p; ro = dof.p; rd = dd.p;
+    }
+    RCQ(ctr.alloc(1));
+    HIPQ(hipMemsetAsync(ctr.p, 0, sizeof(LoadCounters), s));
+    const ExactView x = {t->eq_chr.p, t->eq_pos.p, t->eq_block.p, t->eq_off.p, t->eqi_dir.p, t->eqi_chr.p, t->eqi_pos.p, t->n_eq, t->m_eq};
+    const Contigs ctg = {t->d_start.p, t->d_len.p, (u32)t->len.size()};
+    hipLaunchKernelGGL(k_lookup_equiv, dim3(grid_for(n, 256)), dim3(256), 0, s, x, ctg, t->equiv_hub.p, qc, qp, n, ri, ro, rd, ctr.p);
+    LoadCounters h;
+    HIPQ(hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, s));
+    if (!on_device) {
+        HIPQ(hipMemcpyAsync(class_index, di.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIPQ(hipMemcpyAsync(block_offset, dof.p, n * 2, hipMemcpyDeviceToHost, s));
+        HIPQ(hipMemcpyAsync(dir, dd.p, n, hipMemcpyDeviceToHost, s));
+    }
+    HIPQ(hipStreamSynchronize(s));
+    HIPQ(hipGetLastError());
+    if (h.err_range) return fail(94, "%u positions are in the hub of a class but in none of its ranges (the reference asserts, mappingInference.cpp:6673)", h.err_range);
     return 0;
 }
 

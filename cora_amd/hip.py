@@ -25,7 +25,7 @@ EXPORTS = [
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
     "cora_hip_shard_slot_import", "cora_hip_shard_slot_ptr", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
     "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
-    "cora_hip_tables_export", "cora_hip_tables_destroy",
+    "cora_hip_tables_export", "cora_hip_tables_lookup_equiv", "cora_hip_tables_destroy",
 ]
 
 
@@ -111,6 +111,7 @@ def lib():
         L.cora_hip_tables_get_info.argtypes = [C.c_void_p, C.POINTER(TablesInfo)]
         L.cora_hip_tables_array_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cora_hip_tables_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+        L.cora_hip_tables_lookup_equiv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cora_hip_tables_destroy.argtypes = [C.c_void_p]
         L.cora_hip_tables_destroy.restype = None
         _lib = L

@@ -60,6 +60,17 @@ class LoadedTables:
     def arrays(self):
         return [self.array(n) for n, _ in ARRAYS]
 
+    def lookup_equiv(self, chr_codes, positions):
+        """RetrieveOffsetAndDirInfo (MI:6618-6674) for arrays of (contig code, position): -> (class index, block
+        offset, direction) arrays; class index 0 = the position is in no exact class."""
+        c = np.ascontiguousarray(chr_codes, dtype=np.uint32)
+        p = np.ascontiguousarray(positions, dtype=np.uint32)
+        assert c.shape == p.shape
+        idx, off, dr = np.zeros(len(c), np.uint32), np.zeros(len(c), np.int16), np.zeros(len(c), np.uint8)
+        hip._check(hip.lib().cora_hip_tables_lookup_equiv(self._h, c.ctypes.data, p.ctypes.data, len(c), 0,
+                                                          idx.ctypes.data, off.ctypes.data, dr.ctypes.data))
+        return idx, off, dr
+
     def close(self):
         if self._h:
             hip.lib().cora_hip_tables_destroy(self._h)

@@ -187,6 +187,13 @@ int cora_hip_tables_get_info(const cora_hip_tables *t, cora_hip_tables_info *out
 int cora_hip_tables_array_ptr(const cora_hip_tables *t, int which, const void **device_ptr, uint64_t *n_elems, uint32_t *elem_bytes);
 /* Copies one array to host memory; dst_bytes must be at least n_elems * elem_bytes. */
 int cora_hip_tables_export(const cora_hip_tables *t, int which, void *dst_host, uint64_t dst_bytes);
+/* RetrieveOffsetAndDirInfo (MI:6618-6674) for n positions at once: class_index[i] = 1-based index of the exact class
+ * that covers (chr[i], pos[i]), 0 if none; block_offset[i] / dir[i] = where in the class's block the position sits and
+ * whether it maps to the representative reversed.  on_device != 0: all five arrays are DEVICE pointers (results stay in
+ * HBM for the caller's kernels); otherwise host arrays are copied in and out.  94: a table whose hub names a class that
+ * does not hold the position (the reference asserts). */
+int cora_hip_tables_lookup_equiv(const cora_hip_tables *t, const uint32_t *chr, const uint32_t *pos, uint64_t n, int on_device,
+                                 uint32_t *class_index, int16_t *block_offset, uint8_t *dir);
 void cora_hip_tables_destroy(cora_hip_tables *t);
 
 /* ---- stage-level entry points (used by the parity tests and the benchmark) ---- */

@@ -8,7 +8,11 @@
  * Pinned against the real thing: oracle/_ref/ref_loader (built from the reference's own source by build_ref.sh)
  * dumps the same arrays; tests/golden/manifest.json holds the sha256 of its dumps for the golden tables.
  *
- * usage: loader_oracle [-L] [--exact-only] <Exact> <Inexact> <d> <out.dump> <len of contig 1> [...]
+ *   RetrieveOffsetAndDirInfo MI:6618-6674  which class covers a position, at which block offset, in which direction
+ *
+ * usage: loader_oracle [-L] [--exact-only] [--lookup-all <out.bin>] <Exact> <Inexact> <d> <out.dump> <len of contig 1> [...]
+ * --lookup-all: RetrieveOffsetAndDirInfo for EVERY position of every contig, 8 bytes each: class index u32 (0 = none),
+ * block offset i16, direction u8, 0.
  * The hubs are dense arrays over the concatenated contigs instead of the reference's hash maps; a position the maps
  * would not hold reads 0, which is what every reader of the maps treats "absent" as (MI:1841-1848, 6620-6630).
  * Exit 5: the tables reach outside the contigs (the maps would take any key; the dense hubs cannot).
@@ -57,12 +61,34 @@ static uint64_t hub_index(uint32_t chr, uint32_t pos)
     return starts[chr] + pos - 1;
 }
 
+/* MI:6618-6674 on the flat arrays; the reference's unsigned arithmetic (wrap-around included) and its short offset */
+static uint32_t retrieve_offset_and_dir(const loader_dump *D, uint32_t chr, uint32_t pos, int16_t *off, uint8_t *dir)
+{
+    uint32_t idx = D->equiv_hub[hub_index(chr, pos)];
+    if (idx == 0) return 0;
+    uint32_t i = idx - 1, bl = D->eq_block[i], rp = D->eq_pos[i];
+    if (chr == D->eq_chr[i] && pos >= rp && pos < rp + bl) { *dir = 0; *off = (int16_t)(pos - rp); return idx; }
+    for (uint64_t k = D->eq_off[i]; k < D->eq_off[i + 1]; k++) {
+        uint32_t hp = D->eqi_pos[k];
+        if (chr != D->eqi_chr[k]) continue;
+        if (D->eqi_dir[k] == 0) {
+            if (pos >= hp && pos < hp + bl) { *dir = 0; *off = (int16_t)(pos - hp); return idx; }
+        } else {
+            if (pos <= hp && pos > hp - bl) { *dir = 1; *off = (int16_t)(hp - pos); return idx; }
+        }
+    }
+    fprintf(stderr, "loader_oracle: position %u:%u is in the hub of class %u but in none of its ranges (the reference asserts, MI:6673)\n", chr, pos, idx);
+    exit(7);
+}
+
 int main(int argc, char **argv)
 {
     int cb = 1, exact_only = 0, a = 1;
+    const char *lookup_out = NULL;
     for (; a < argc && argv[a][0] == '-'; a++) {
         if (!strcmp(argv[a], "-L")) cb = 2;
         else if (!strcmp(argv[a], "--exact-only")) exact_only = 1;   /* the BEST mapping modes, MI:1090-1093, 1139-1152 */
+        else if (!strcmp(argv[a], "--lookup-all") && a + 1 < argc) lookup_out = argv[++a];
     }
     if (argc - a < 5) { fprintf(stderr, "usage: loader_oracle [-L] [--exact-only] Exact Inexact d out.dump len1 [len2 ...]\n"); return 2; }
     const char *fx = argv[a], *fi = argv[a + 1], *out = argv[a + 3];
@@ -153,6 +179,20 @@ int main(int argc, char **argv)
                 D.hom_hub[t] = D.hom_hub[hub_index(rc, rp + j)];
             }
         }
+    }
+    if (lookup_out) {
+        FILE *f = fopen(lookup_out, "wb");
+        if (!f) { perror(lookup_out); return 3; }
+        for (int c = 1; c <= nc; c++)
+            for (uint32_t p = 1; p <= lens[c]; p++) {
+                int16_t off = 0; uint8_t dir = 0;
+                uint32_t idx = retrieve_offset_and_dir(&D, (uint32_t)c, p, &off, &dir);
+                uint8_t r[8] = {(uint8_t)idx, (uint8_t)(idx >> 8), (uint8_t)(idx >> 16), (uint8_t)(idx >> 24),
+                                (uint8_t)off, (uint8_t)((uint16_t)off >> 8), idx ? dir : 0, 0};
+                if (!idx) r[4] = r[5] = 0;
+                fwrite(r, 1, 8, f);
+            }
+        fclose(f);
     }
     return loader_dump_write(&D, out) ? 3 : 0;
 }

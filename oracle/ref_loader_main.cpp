@@ -70,6 +70,22 @@ int main(int argc, char **argv)
         }
     }
     if (outside) fprintf(stderr, "ref_loader: %llu hub entries outside the contigs\n", outside);
+    // CORA_REF_LOOKUP_ALL=<file>: RetrieveOffsetAndDirInfo (mappingInference.cpp:6618-6674) for every position of every
+    // contig, 8 bytes each: class index u32 (0 = none), block offset i16, direction u8, 0
+    if (const char *lk = getenv("CORA_REF_LOOKUP_ALL")) {
+        FILE *f = fopen(lk, "wb");
+        if (!f) { perror(lk); return 3; }
+        for (int c = 1; c <= nc; c++)
+            for (unsigned long long p = 1; p <= len[c]; p++) {
+                short off = 0; bool dir = 0;
+                unsigned int idx = RetrieveOffsetAndDirInfo((unsigned int)c, (unsigned int)p, off, dir);
+                if (!idx) { off = 0; dir = 0; }
+                unsigned char r[8] = {(unsigned char)idx, (unsigned char)(idx >> 8), (unsigned char)(idx >> 16), (unsigned char)(idx >> 24),
+                                      (unsigned char)off, (unsigned char)((unsigned short)off >> 8), (unsigned char)dir, 0};
+                fwrite(r, 1, 8, f);
+            }
+        fclose(f);
+    }
     int rc = loader_dump_write(&D, argv[5]);
     return rc ? 3 : (outside ? 4 : 0);
 }

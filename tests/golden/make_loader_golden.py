@@ -181,9 +181,11 @@ def contig_lengths(inp):
     return [len(s) for _, s in make_golden.INPUTS[inp]()]
 
 
-def run_ref(L, d, K, ex, inx, lens, out, exact_only=False):
-    r = subprocess.run([ref_loader(L, d), ex, inx, str(K), str(d), out] + [str(x) for x in lens],
-                       env=dict(os.environ, CORA_REF_EXACT_ONLY="1" if exact_only else "0"),
+def run_ref(L, d, K, ex, inx, lens, out, exact_only=False, lookup=None):
+    env = dict(os.environ, CORA_REF_EXACT_ONLY="1" if exact_only else "0")
+    if lookup:
+        env["CORA_REF_LOOKUP_ALL"] = lookup
+    r = subprocess.run([ref_loader(L, d), ex, inx, str(K), str(d), out] + [str(x) for x in lens], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise SystemExit("ref_loader failed (%d): %s" % (r.returncode, r.stdout[-2000:]))
@@ -217,8 +219,11 @@ def main():
         else:
             dirn = os.path.join(HERE, "cases", name)
         out = os.path.join(tmp, name + ".dump")
-        run_ref(c["L"], c["d"], c["K"], os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), lens_of[inp], out)
+        lk = os.path.join(tmp, name + ".lookup")
+        run_ref(c["L"], c["d"], c["K"], os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), lens_of[inp], out, lookup=lk)
         c["loader_sha256"] = sha256(out)
+        c["lookup_sha256"] = sha256(lk)
+        os.remove(lk)
         c["contig_lengths"] = lens_of[inp]
         print("%-22s loaded image %10d B  %s" % (name, os.path.getsize(out), c["loader_sha256"][:16]), flush=True)
         os.remove(out)
@@ -230,11 +235,12 @@ def main():
             shutil.rmtree(dirn)
         write_tables(dirn, records, nodes, L, d)
         out = os.path.join(dirn, "reference.dump")
-        run_ref(L, d, 50, os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), lens, out)
+        lk = os.path.join(tmp, name + ".lookup")
+        run_ref(L, d, 50, os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), lens, out, lookup=lk)
         eo = os.path.join(tmp, name + ".exact_only.dump")
         run_ref(L, d, 50, os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), lens, eo, exact_only=True)
         manifest["loader_cases"][name] = {"L": L, "d": d, "contig_lengths": lens, "records": len(records), "nodes": len(nodes),
-                                          "loader_sha256": sha256(out), "loader_exact_only_sha256": sha256(eo)}
+                                          "loader_sha256": sha256(out), "loader_exact_only_sha256": sha256(eo), "lookup_sha256": sha256(lk)}
         print("%-22s %4d records %5d nodes  loaded image %8d B" % (name, len(records), len(nodes), os.path.getsize(out)), flush=True)
     json.dump(manifest, open(mpath, "w"), indent=1, sort_keys=True)
     shutil.rmtree(tmp)

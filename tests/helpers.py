@@ -110,8 +110,10 @@ def build_loader_oracle():
     return LOADER_ORACLE
 
 
-def run_loader_oracle(exact, inexact, d, lens, out, L=False, exact_only=False):
+def run_loader_oracle(exact, inexact, d, lens, out, L=False, exact_only=False, lookup_all=None):
     cmd = [build_loader_oracle()] + (["-L"] if L else []) + (["--exact-only"] if exact_only else [])
+    if lookup_all:
+        cmd += ["--lookup-all", lookup_all]
     r = subprocess.run(cmd + [exact, inexact, str(d), out] + [str(x) for x in lens], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     return r
 

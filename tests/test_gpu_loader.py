@@ -59,6 +59,33 @@ def test_handmade_tables_load_like_the_reference(name):
     t.close()
 
 
+def _lookup_bytes(t, lens):
+    """RetrieveOffsetAndDirInfo for every position of every contig, in the 8-byte layout of the oracle's --lookup-all."""
+    chr_codes = np.concatenate([np.full(n, c + 1, dtype=np.uint32) for c, n in enumerate(lens)]) if lens else np.zeros(0, np.uint32)
+    pos = np.concatenate([np.arange(1, n + 1, dtype=np.uint32) for n in lens]) if lens else np.zeros(0, np.uint32)
+    idx, off, dr = t.lookup_equiv(chr_codes, pos)
+    rec = np.zeros(len(idx), dtype=[("idx", "<u4"), ("off", "<i2"), ("dir", "u1"), ("pad", "u1")])
+    rec["idx"], rec["off"], rec["dir"] = idx, off, dr
+    return rec.tobytes()
+
+
+@pytest.mark.parametrize("name", CASES + ["loader:" + n for n in LCASES])
+def test_class_lookup_of_every_position_matches_the_reference(name):
+    import hashlib
+    if name.startswith("loader:"):
+        c = H.MANIFEST["loader_cases"][name[7:]]
+        dirn = os.path.join(H.LOADER_CASES, name[7:])
+    else:
+        c, dirn = H.golden_case(name)
+    t = tables.load_homology_tables(os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), c["d"], c["contig_lengths"], chr_short=c["L"])
+    got = _lookup_bytes(t, c["contig_lengths"])
+    assert hashlib.sha256(got).hexdigest() == c["lookup_sha256"]
+    # keys the reference's maps could not hold are "not found"
+    idx, off, dr = t.lookup_equiv([0, 1, len(c["contig_lengths"]) + 1, 1], [5, 0, 1, c["contig_lengths"][0] + 1])
+    assert not idx.any() and not off.any() and not dr.any()
+    t.close()
+
+
 def _order_matters(records, nodes):
     """True if homHub depends on the order of the copies (MI:1123, 1133): a position copied from is also copied to
     by some other copy, or two copies put different values on one position."""
@@ -199,6 +226,16 @@ def test_tables_of_a_job_load_without_files():
     assert info["exact_records"] == c["exact_nodes"] and info["inexact_nodes"] == c["inexact_nodes"]
     assert info["serial_hub_replay"] == 0
     assert H.dump_sha256(t.arrays()) == c["loader_sha256"]
+    # every one of the 64 M positions through the class lookup, against the oracle's
+    ex, en, inx, inn = job.tables()
+    dirn = os.path.join(H.scratch(), "job_tables")
+    os.makedirs(dirn, exist_ok=True)
+    for fn, data in (("Exact", ex), ("Inexact", inx), ("Exact.itemCount", b"%d\n" % en), ("Inexact.itemCount", b"%d\n" % inn)):
+        open(os.path.join(dirn, fn), "wb").write(data)
+    lk = os.path.join(dirn, "lookup.bin")
+    r = H.run_loader_oracle(os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), c["d"], c["contig_lengths"], os.path.join(dirn, "o.dump"), lookup_all=lk)
+    assert r.returncode == 0, r.stdout
+    assert _lookup_bytes(t, c["contig_lengths"]) == H.read(lk)
     print("loader: parse %.3f ms, reverse lookups %.3f ms, hubs %.3f ms, total %.3f ms, %.1f MB in HBM" % (
         info["ms_parse"], info["ms_lookups"], info["ms_hubs"], info["ms_total"], info["device_bytes"] / 1e6))
     t.close()

@@ -15,9 +15,9 @@ CASES = sorted(n for n, c in H.MANIFEST["cases"].items() if not c.get("hash_only
 LCASES = sorted(H.MANIFEST["loader_cases"])
 
 
-def oracle_dump(exact, inexact, d, lens, L, name, exact_only=False):
+def oracle_dump(exact, inexact, d, lens, L, name, exact_only=False, lookup_all=None):
     out = os.path.join(H.scratch(), "loader_%s%s.dump" % (name, "_eo" if exact_only else ""))
-    r = H.run_loader_oracle(exact, inexact, d, lens, out, L=L, exact_only=exact_only)
+    r = H.run_loader_oracle(exact, inexact, d, lens, out, L=L, exact_only=exact_only, lookup_all=lookup_all)
     assert r.returncode == 0, r.stdout
     return out
 
@@ -25,15 +25,19 @@ def oracle_dump(exact, inexact, d, lens, L, name, exact_only=False):
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_matches_reference_loader_on_golden_tables(name):
     c, dirn = H.golden_case(name)
-    out = oracle_dump(os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), c["d"], c["contig_lengths"], c["L"], name)
+    lk = os.path.join(H.scratch(), "lookup_%s.bin" % name)
+    out = oracle_dump(os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), c["d"], c["contig_lengths"], c["L"], name, lookup_all=lk)
     assert H.sha256(out) == c["loader_sha256"]
+    assert H.sha256(lk) == c["lookup_sha256"], "RetrieveOffsetAndDirInfo over every position differs from the reference's"
 
 
 @pytest.mark.parametrize("name", LCASES)
 def test_oracle_matches_reference_loader_on_handmade_tables(name):
     c = H.MANIFEST["loader_cases"][name]
     dirn = os.path.join(H.LOADER_CASES, name)
-    out = oracle_dump(os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), c["d"], c["contig_lengths"], c["L"], name)
+    lk = os.path.join(H.scratch(), "lookup_%s.bin" % name)
+    out = oracle_dump(os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), c["d"], c["contig_lengths"], c["L"], name, lookup_all=lk)
+    assert H.sha256(lk) == c["lookup_sha256"], "RetrieveOffsetAndDirInfo over every position differs from the reference's"
     H.assert_same_arrays(H.read_dump(out), H.read_dump(os.path.join(dirn, "reference.dump")), name)
     assert H.sha256(out) == c["loader_sha256"] == H.sha256(os.path.join(dirn, "reference.dump"))
     eo = oracle_dump(os.path.join(dirn, "Exact"), os.path.join(dirn, "Inexact"), c["d"], c["contig_lengths"], c["L"], name, exact_only=True)
