@@ -175,6 +175,20 @@ inline int write_counters(cora_hip_job *job, const DevCounters &h)
 #define ZERO_COUNTERS(job, field, n) HIPQ(hipMemsetAsync((char *)(job)->ctr.p + offsetof(DevCounters, field), 0, 8 * (n), (job)->stream))
 #define FORMAT_ERROR_CHECK(h) do { if ((h).format_errors) return fail(51, "FASTA image does not have the fixed line width the reference's loader assumes (%llu misplaced line ends)", (unsigned long long)(h).format_errors); } while (0)
 
+// CORA_TRACE=2: wall time between marks, each mark synchronising the stream first (for finding where a run loses time)
+inline void trace_mark(cora_hip_job *job, const char *what, int idx = -1)
+{
+    static const int level = getenv("CORA_TRACE") ? atoi(getenv("CORA_TRACE")) : 0;
+    static const int mask = getenv("CORA_SYNC_MASK") ? atoi(getenv("CORA_SYNC_MASK")) : 0;
+    if (idx >= 0 && ((mask >> idx) & 1)) (void)hipStreamSynchronize(job->stream);
+    if (level < 2) return;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    (void)hipStreamSynchronize(job->stream);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cora]   %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+}
+
 inline int bits_for(u64 G)
 {
     int b = 1;

@@ -299,13 +299,17 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         DBuf<u64> ik_tmp, nexcl, scr, tot;
         DBuf<u32> im_tmp, hf, nstart;
         DBuf<int16_t> blen;
+        trace_mark(job, "items: enter", 0);
         RCQ(ik_tmp.alloc(M)); RCQ(im_tmp.alloc(M));
+        trace_mark(job, "items: sort buffers", 1);
         SortArrays kk, kt;
         kk.a = ik.p; kk.c = im.p; kt.a = ik_tmp.p; kt.c = im_tmp.p;
         const int gb = bits_for(dp.G);
         if (radix_sort(s, kk, kt, M, 0, gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
         if (radix_sort(s, kk, kt, M, 32, 32 + gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+        trace_mark(job, "items: two sorts", 2);
         RCQ(hf.alloc(M)); RCQ(nexcl.alloc(M)); RCQ(scr.alloc(scan_scratch_elems(M))); RCQ(tot.alloc(1)); RCQ(blen.alloc(M));
+        trace_mark(job, "items: flag buffers", 3);
         DevCounters h;
         ZERO_COUNTERS(job, n_dirty, 1);
         launch_node_flags(s, kk.a, M, hf.p, job->ctr.p);
@@ -321,6 +325,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         RCQ(succ.alloc(M));
         launch_chain(s, dp, kk.a, kk.c, hf.p, nexcl.p, nstart.p, (u32)n_nodes, M, succ.p, blen.p);
         HIPQ(hipGetLastError());
+        trace_mark(job, "items: lists + chains", 4);
         // ---- bytes: lists the device can order itself are written here; the others go to the host (kernels.hip) ----
         const int cw = job->prm.chr_short ? 2 : 1;
         const u32 nn = (u32)n_nodes;
@@ -341,6 +346,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         u64 totals[3] = {0, 0, 0};                          // stream bytes, host lists, their items
         HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
+        trace_mark(job, "items: sizes + scans", 5);
         DBuf<u8> stream;
         DBuf<HostNode> hnodes;
         DBuf<u64> hk;
@@ -352,6 +358,11 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, nn, nsize.p, noff.p, hflag.p, hidx.p, hoff.p, node_tie.p, stream.p,
                           hnodes.p, hk.p, hm.p, hbl.p, ord.p);
         HIPQ(hipGetLastError());
+        // Wait for the kernels BEFORE queueing the copies to the host.  Queued behind pending kernels, these copies made
+        // the second run of every job 5.5 ms slower (once: a runtime-internal set-up on that path; bisected with
+        // CORA_SYNC_MASK).  The copies need the kernels' results anyway, so the wait costs nothing.
+        HIPQ(hipStreamSynchronize(s));
+        trace_mark(job, "items: write bytes", 6);
         RCQ(d2h(job, job->h_stream, stream_host, (const u8 *)stream.p, totals[0]));
         RCQ(d2h(job, job->h_hnodes, hnodes_host, (const HostNode *)hnodes.p, totals[1]));
         RCQ(d2h(job, job->h_key, ir.key, (const u64 *)hk.p, totals[2]));
@@ -362,6 +373,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         big_nodes = h.big_nodes;
         if (h.n_dirty) RCQ(d2h(job, job->h_packed, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
         HIPQ(hipStreamSynchronize(s));
+        trace_mark(job, "items: copies to host", 7);
         // list starts of the compacted host items
         RCQ(job->h_node_start.reserve(totals[1] + 1));
         for (u64 i = 0; i < totals[1]; i++) job->h_node_start.p[i] = (u32)hnodes_host[i].item_off;
