@@ -370,6 +370,27 @@ extern "C" int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const voi
     return 0;
 }
 
+// Sizes a receive slot for n elements and returns its device address, so that the caller's collective can deliver straight
+// into the library's memory (no staging tensor, no copy).  The data must be there before the next stage call.
+extern "C" int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t n, void **ptr)
+{
+    if (!job || !job->shard || !ptr) return fail(19, "cora_hip_shard_begin has not run");
+    PoolScope scope(&job->pool);
+    ShardState &sh = *job->shard;
+    switch (slot) {
+    case SLOT_RECV_A: RCQ(sh.recv_a.alloc(n)); sh.n_recv = n; *ptr = sh.recv_a.p; break;
+    case SLOT_RECV_C: if (n != sh.n_recv) return fail(19, "RECV_C must match RECV_A"); RCQ(sh.recv_c.alloc(n)); *ptr = sh.recv_c.p; break;
+    case SLOT_RX_CLS: RCQ(sh.rparts.cls.alloc(n)); sh.rparts.NNS = n; *ptr = sh.rparts.cls.p; break;
+    case SLOT_RX_CNT: if (n != sh.rparts.NNS) return fail(19, "RX_CNT must match RX_CLS"); RCQ(sh.rparts.ce.alloc(n)); *ptr = sh.rparts.ce.p; break;
+    case SLOT_RX_ENT: RCQ(sh.rparts.ent.alloc(n)); sh.rparts.NE = n; *ptr = sh.rparts.ent.p; break;
+    case SLOT_RX_DIR: if (n != sh.rparts.NE) return fail(19, "RX_DIR must match RX_ENT"); RCQ(sh.rparts.edir.alloc(n)); *ptr = sh.rparts.edir.p; break;
+    case SLOT_RX_F2: RCQ(sh.f2_all.alloc(n)); sh.n_f2_all = n; *ptr = sh.f2_all.p; break;
+    default: return fail(19, "slot %d cannot be reserved", slot);
+    }
+    HIPQ(hipStreamSynchronize(job->stream));
+    return 0;
+}
+
 // first singleton of this rank's classes in the reference's class-id order (Q3); ~0 = none
 extern "C" int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key)
 {

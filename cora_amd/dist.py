@@ -58,6 +58,10 @@ class Comm:
         dist.all_to_all_single(recv, send)
         return [int(x) for x in recv.tolist()]
 
+    def all_to_all_into(self, recv, send, send_counts, recv_counts):
+        """Device tensors only (nccl): the records land in `recv`, which the caller owns."""
+        dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+
     def all_to_all(self, send, send_counts, recv_counts):
         if self.local:
             return send
@@ -119,19 +123,36 @@ class ShardedJob:
         hip._check(self.lib.cora_hip_shard_stage(self.h, stage, arg, counts))
         return [int(counts[r]) for r in range(self.comm.world)]
 
+    def _reserve(self, slot, n, like):
+        """The receive slot sized for n elements, as a tensor over the library's memory."""
+        ptr = C.c_void_p()
+        hip._check(self.lib.cora_hip_shard_slot_reserve(self.h, slot, n, C.byref(ptr)))
+        if n == 0 or not ptr.value:
+            return torch.empty(0, dtype=like.dtype, device=self.comm.device)
+        return torch.as_tensor(_DeviceArray(ptr.value, n, like.element_size()), device=self.comm.device)
+
+    def _move(self, src, dst, counts, recv_counts):
+        send = self._view(src)
+        if self.comm.local or self.comm.staged:
+            self._import(dst, self.comm.all_to_all(send, counts, recv_counts))
+            return
+        # RCCL: straight from the library's send slot into its receive slot, no tensor in between
+        recv = self._reserve(dst, sum(recv_counts), send)
+        self.comm.all_to_all_into(recv, send, counts, recv_counts)
+        torch.cuda.synchronize()
+
     def _route(self, pairs, counts):
         """pairs: [(send slot, recv slot)]; counts[r] records of each send slot go to rank r."""
         recv_counts = self.comm.exchange_counts(counts)
         for src, dst in pairs:
-            self._import(dst, self.comm.all_to_all(self._view(src), counts, recv_counts))
+            self._move(src, dst, counts, recv_counts)
 
     def _gather_to_root(self, pairs):
         """Each (send slot, recv slot) may have its own length: everything goes to rank 0."""
         for src, dst in pairs:
-            t = self._view(src)
-            counts = [t.numel()] + [0] * (self.comm.world - 1)
-            recv_counts = self.comm.exchange_counts(counts)
-            self._import(dst, self.comm.all_to_all(t, counts, recv_counts))
+            n = self._view(src).numel()
+            counts = [n] + [0] * (self.comm.world - 1)
+            self._move(src, dst, counts, self.comm.exchange_counts(counts))
 
     def run(self):
         c, lib, h = self.comm, self.lib, self.h

@@ -124,6 +124,9 @@ int cora_hip_shard_slot_export(cora_hip_job *job, int slot, void *dst_device);
 /* Device address of a slot's data, valid until the job's next stage or import call (send without a copy). */
 int cora_hip_shard_slot_ptr(cora_hip_job *job, int slot, void **ptr);
 int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const void *src_device, uint64_t n_elems);
+/* Sizes a receive slot (RECV_*, RX_*) for n_elems and returns its device address: the caller's collective then delivers
+ * straight into the library's memory instead of into a tensor that slot_import would copy. */
+int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t n_elems, void **ptr);
 int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
 int cora_hip_shard_set_first_singleton(cora_hip_job *job, uint64_t key);
 
