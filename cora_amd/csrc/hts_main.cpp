@@ -149,49 +149,51 @@ int main(int argc, char **argv)
         std::cout << "ERROR: Reference file is not properly formatted..." << std::endl;
         return 51;
     }
-    {
-        size_t p = 0;
-        auto skip_ws = [&]() { while (p < image_bytes && isspace(image[p])) p++; };
-        auto skip_tok = [&]() { size_t a = p; while (p < image_bytes && !isspace(image[p])) p++; return p - a; };
-        skip_ws(); skip_tok(); skip_ws();
-        prm.line_width = (int)skip_tok();
-        std::cout << "Reference line length: " << prm.line_width << "bp .." << std::endl;
-        if (prm.line_width < 1) { std::cout << "ERROR: Reference file is not properly formatted..." << std::endl; return 51; }
-    }
-    std::vector<cora_hip_contig> contigs;
+    // contig names and lengths as the .fai gives them (HTS:171-197; exit 52 without it)
+    std::vector<long long> fai_len;
     {
         std::ifstream fai((ref_path + ".fai").c_str());
         if (!fai.is_open()) { std::cout << "Could not find fai file for reference file: " << ref_path << std::endl; return 52; }
         std::string line;
-        size_t cursor = 0;
-        const size_t W = (size_t)prm.line_width;
         while (std::getline(fai, line)) {
             std::stringstream ss(line);
             std::string name;
             long long size = 0;
             ss >> name >> size;
             if (name.empty()) continue;
-            if (cursor >= image_bytes || image[cursor] != '>') {
-                std::cout << "ERROR: contig " << contigs.size() + 1 << " (" << name << ") does not start where the .fai lengths and the fixed line width put it" << std::endl;
-                return 51;
-            }
-            const void *nl = memchr(image + cursor, '\n', image_bytes - cursor);
-            if (!nl || size <= 0) { std::cout << "ERROR: Reference file is not properly formatted..." << std::endl; return 51; }
-            cora_hip_contig c;
-            c.file_offset = (uint64_t)((const uint8_t *)nl - image) + 1;
-            c.length = (uint32_t)size;
-            c.reserved = 0;
-            contigs.push_back(c);
-            cursor = c.file_offset + (size_t)size + ((size_t)size + W - 1) / W;
+            fai_len.push_back(size);
         }
     }
-    if (contigs.empty()) { std::cout << "ERROR: empty .fai" << std::endl; return 52; }
+    if (fai_len.empty()) { std::cout << "ERROR: empty .fai" << std::endl; return 52; }
 
     int rc = cora_hip_init(0);
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
+    // The image is scanned on the GPU (lines, headers, contig lengths: cora_hip_fasta_scan).  A file in the layout
+    // ReadReference assumes (HTS:96-142: one line width) is read in place; any other is gathered first, where the
+    // reference would silently mis-load it.  The .fai must describe the same contigs.
+    cora_hip_fasta *fa = nullptr;
+    rc = cora_hip_fasta_scan(image, image_bytes, &fa);
+    if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
+    cora_hip_fasta_info fin;
+    cora_hip_fasta_get_info(fa, &fin);
+    std::cout << "Reference line length: " << fin.line_width << "bp .." << (fin.conforming ? "" : " (lines of other lengths present)") << std::endl;
+    if (fin.contigs != fai_len.size()) {
+        std::cout << "ERROR: the .fai lists " << fai_len.size() << " contigs, the reference holds " << fin.contigs << std::endl;
+        return 51;
+    }
+    for (size_t c = 0; c < fai_len.size(); c++) {
+        uint64_t len = 0;
+        cora_hip_fasta_contig(fa, (int32_t)c, nullptr, &len, nullptr, nullptr);
+        if ((long long)len != fai_len[c]) {
+            std::cout << "ERROR: contig " << c + 1 << " has " << len << " bases, the .fai says " << fai_len[c] << std::endl;
+            return 51;
+        }
+    }
+    prm.line_width = 1;                                      // unused on this path
     cora_hip_job *job = nullptr;
     rc = cora_hip_job_create(&prm, &job);
-    if (!rc) rc = cora_hip_job_set_reference(job, image, image_bytes, contigs.data(), (int32_t)contigs.size());
+    if (!rc) rc = cora_hip_job_set_reference_fasta(job, fa);
+    cora_hip_fasta_destroy(fa);
     if (!rc) rc = cora_hip_job_run(job);
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
 

@@ -69,6 +69,14 @@ extern "C" int cora_hip_job_set_reference(cora_hip_job *job, const uint8_t *imag
                                           const cora_hip_contig *contigs, int32_t n_contigs)
 {
     if (!job || !image || !contigs || n_contigs <= 0) return fail(51, "bad reference arguments");
+    return set_reference_impl(job, contigs, n_contigs, (u32)job->prm.line_width, image_bytes, image, nullptr, nullptr);
+}
+
+// The image comes from host memory (copied), from device memory (copied), or as a device buffer that the job takes over.
+int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_t n_contigs, u32 W, size_t image_bytes,
+                       const uint8_t *host_image, const uint8_t *dev_image, DBuf<u8> *adopt)
+{
+    if (!job || !contigs || n_contigs <= 0 || W < 1) return fail(51, "bad reference arguments");
     if (!job->prm.chr_short && n_contigs > 127)
         return fail(19, "%d contigs need the 2-byte layout (homTable_setup_L; cora.cpp:25,488-493)", n_contigs);
     if (n_contigs > 65530) return fail(19, "too many contigs (%d)", n_contigs);                                            // HTS:23-27
@@ -77,7 +85,6 @@ extern "C" int cora_hip_job_set_reference(cora_hip_job *job, const uint8_t *imag
     hg.len.assign(n_contigs, 0);
     std::vector<u64> off(n_contigs);
     u64 g = 0, bases = 0;
-    const u32 W = (u32)job->prm.line_width;
     for (int c = 0; c < n_contigs; c++) {
         const u64 L = contigs[c].length;
         if (L <= (u64)job->prm.K)
@@ -95,8 +102,15 @@ extern "C" int cora_hip_job_set_reference(cora_hip_job *job, const uint8_t *imag
     plan_windows(hg.d, hg.len, hg.window);
     job->genome_bases = bases;
 
-    RCQ(job->raw.alloc(image_bytes + 16));
-    HIPQ(hipMemcpyAsync(job->raw.p, image, image_bytes, hipMemcpyHostToDevice, job->stream));
+    if (adopt) {
+        job->raw.release();
+        job->raw.p = adopt->p; job->raw.n = adopt->n; job->raw.pool = adopt->pool;
+        adopt->p = nullptr; adopt->n = 0;
+    } else {
+        RCQ(job->raw.alloc(image_bytes + 16));
+        if (host_image) HIPQ(hipMemcpyAsync(job->raw.p, host_image, image_bytes, hipMemcpyHostToDevice, job->stream));
+        else HIPQ(hipMemcpyAsync(job->raw.p, dev_image, image_bytes, hipMemcpyDeviceToDevice, job->stream));
+    }
     RCQ(job->d_gstart.alloc(n_contigs + 1));
     RCQ(job->d_off.alloc(n_contigs));
     RCQ(job->d_len.alloc(n_contigs));

@@ -240,3 +240,5 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
                    u32 *sketch = nullptr /* [n] per-record sketches for k_verify's pre-filter; sorted along */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
+int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_t n_contigs, u32 W, size_t image_bytes,
+                       const uint8_t *host_image, const uint8_t *dev_image, DBuf<u8> *adopt);

@@ -26,6 +26,8 @@ EXPORTS = [
     "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
     "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
     "cora_hip_tables_export", "cora_hip_tables_lookup_equiv", "cora_hip_tables_destroy",
+    "cora_hip_fasta_scan", "cora_hip_fasta_get_info", "cora_hip_fasta_fai_text", "cora_hip_fasta_contig",
+    "cora_hip_fasta_destroy", "cora_hip_job_set_reference_fasta",
 ]
 
 
@@ -55,6 +57,14 @@ class TablesInfo(C.Structure):
         "exact_records", "exact_entries", "inexact_nodes", "inexact_items", "hub_positions", "device_bytes",
         "serial_hub_replay")] + [("d", C.c_int32), ("chr_short", C.c_int32)] + [(n, C.c_float) for n in (
         "ms_parse", "ms_lookups", "ms_hubs", "ms_total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class FastaInfo(C.Structure):
+    _fields_ = [("image_bytes", C.c_uint64), ("lines", C.c_uint64), ("contigs", C.c_uint64), ("bases", C.c_uint64),
+                ("conforming", C.c_int32), ("line_width", C.c_int32), ("ms_scan", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -115,6 +125,14 @@ def lib():
         L.cora_hip_tables_lookup_equiv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cora_hip_tables_destroy.argtypes = [C.c_void_p]
         L.cora_hip_tables_destroy.restype = None
+        L.cora_hip_fasta_scan.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.cora_hip_fasta_get_info.argtypes = [C.c_void_p, C.POINTER(FastaInfo)]
+        L.cora_hip_fasta_fai_text.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.cora_hip_fasta_contig.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.cora_hip_fasta_destroy.argtypes = [C.c_void_p]
+        L.cora_hip_fasta_destroy.restype = None
+        L.cora_hip_job_set_reference_fasta.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -188,6 +206,42 @@ def fasta_geometry(image: bytes, fai_path: str):
     return W, contigs
 
 
+class Fasta:
+    """A FASTA image scanned on the device: the contig index of `cora faiGenerate` (cora.cpp:1006-1029)."""
+
+    def __init__(self, image: bytes):
+        self._h = C.c_void_p()
+        self._n = len(image)
+        buf = (C.c_char * max(len(image), 1)).from_buffer_copy(image or b"\0")
+        _check(lib().cora_hip_fasta_scan(C.cast(buf, C.c_void_p), len(image), C.byref(self._h)))
+
+    def info(self):
+        fi = FastaInfo()
+        _check(lib().cora_hip_fasta_get_info(self._h, C.byref(fi)))
+        return fi.as_dict()
+
+    def fai_text(self) -> bytes:
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().cora_hip_fasta_fai_text(self._h, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def contig(self, i):
+        name, ln, off, lb = C.c_char_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().cora_hip_fasta_contig(self._h, i, C.byref(name), C.byref(ln), C.byref(off), C.byref(lb)))
+        return name.value, ln.value, off.value, lb.value
+
+    def close(self):
+        if self._h:
+            lib().cora_hip_fasta_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Job:
     """One reference, one device: set_reference() uploads, run() builds both tables."""
 
@@ -226,6 +280,19 @@ class Job:
         buf = (C.c_char * len(image)).from_buffer_copy(image) if not isinstance(image, np.ndarray) else None
         ptr = C.cast(buf, C.c_void_p) if buf is not None else C.c_void_p(image.ctypes.data)
         _check(lib().cora_hip_job_set_reference(self._h, ptr, len(image), arr, len(contigs)))
+
+    def set_reference_fasta(self, image: bytes):
+        """No .fai, no fixed line width: contigs come from the device scan of the image."""
+        if not self._h:
+            self._create(1)
+        fa = Fasta(image)
+        try:
+            self.fasta_info = fa.info()
+            self.n_contigs = self.fasta_info["contigs"]
+            self._image = image
+            _check(lib().cora_hip_job_set_reference_fasta(self._h, fa._h))
+        finally:
+            fa.close()
 
     def run(self):
         _check(lib().cora_hip_job_run(self._h))

@@ -199,6 +199,37 @@ int cora_hip_tables_lookup_equiv(const cora_hip_tables *t, const uint32_t *chr, 
                                  uint32_t *class_index, int16_t *block_offset, uint8_t *dir);
 void cora_hip_tables_destroy(cora_hip_tables *t);
 
+/* ---- the reference side's file handling: contig index and a loader for any FASTA ----
+ * Replaces `cora faiGenerate` (/root/reference/cora.cpp:1006-1029, an awk program run through system()) and lifts
+ * the fixed-line-width restriction of ReadReference (HTS:96-142).  The file image is scanned on the GPU: separator
+ * positions, one thread per line, scans for header rank and sequence bytes, one record per contig. */
+typedef struct cora_hip_fasta cora_hip_fasta;   /* opaque: the image in HBM and its line / contig index */
+
+typedef struct cora_hip_fasta_info {
+    uint64_t image_bytes, lines, contigs, bases;   /* bases = sum of the contig lengths the .fai reports */
+    int32_t conforming;      /* 1: headers start their lines and every contig's lines hold line_width bytes but its last
+                                (1..line_width): the layout ReadReference assumes, read in place without a copy */
+    int32_t line_width;      /* lineBases of the first contig (cora.cpp:1023), 0 if it has no sequence line */
+    float ms_scan;           /* HIP events; image already in HBM when the clock starts */
+} cora_hip_fasta_info;
+
+/* Scans a FASTA file image (host memory; copied to HBM). */
+int cora_hip_fasta_scan(const uint8_t *image, size_t image_bytes, cora_hip_fasta **out);
+int cora_hip_fasta_get_info(const cora_hip_fasta *f, cora_hip_fasta_info *out);
+/* The bytes `cora faiGenerate` writes to <ref>.fai for this file: name, length, offset, lineBases, lineBases + 1 per
+ * contig, byte for byte what the awk program prints (stale lineBases after an empty contig and the single line for
+ * a file without any header included).  Valid until destroy. */
+int cora_hip_fasta_fai_text(const cora_hip_fasta *f, const char **text, size_t *bytes);
+/* One contig of the index (any output pointer may be NULL). */
+int cora_hip_fasta_contig(const cora_hip_fasta *f, int32_t index, const char **name, uint64_t *length, uint64_t *offset,
+                          uint64_t *line_bases);
+void cora_hip_fasta_destroy(cora_hip_fasta *f);
+/* cora_hip_job_set_reference without a .fai and without the fixed line width: contigs and lengths come from the scan
+ * (a contig's bases = the first blank-delimited token of each of its lines, which is what the .fai length counts).
+ * A conforming file is read in place exactly as cora_hip_job_set_reference reads it, so the tables are the same
+ * bytes; any other file is first gathered into a dense image on the GPU.  The job's params.line_width is ignored. */
+int cora_hip_job_set_reference_fasta(cora_hip_job *job, const cora_hip_fasta *f);
+
 /* ---- stage-level entry points (used by the parity tests and the benchmark) ---- */
 
 /* Stable LSD radix sort of n records on device memory, keyed on bits

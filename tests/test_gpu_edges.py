@@ -33,12 +33,17 @@ def _build(fa, K, d, p=1, t=1, L=False, sharded=False):
         job.close()
 
 
-def test_ragged_fasta_is_refused(tmp_path):
-    """The reference's loader assumes one line width (HTS:96-142) and silently mis-loads anything else."""
+def test_ragged_fasta_is_refused_by_the_fai_path_and_read_by_the_scan(tmp_path):
+    """The reference's loader assumes one line width (HTS:96-142) and silently mis-loads anything else.  The C-ABI
+    entry that mirrors it (.fai + line width) refuses such a file; the executable, which scans the file on the GPU
+    (cora_hip_fasta_scan), builds the tables of the same sequence in fixed-width layout."""
     rs = np.random.RandomState(1)
     seq = synth.random_seq(rs, 3000)
+    seq[1000:1400] = seq[200:600]                # something to find
     fa = str(tmp_path / "ragged.fa")
+    good = str(tmp_path / "good.fa")
     synth.write_fasta(fa, [("c1", seq)], 60)
+    synth.write_fasta(good, [("c1", seq)], 60)
     text = open(fa).read().split("\n")
     text[5] = text[5] + text[6][:7]              # one long line, the next one short
     text[6] = text[6][7:]
@@ -47,9 +52,11 @@ def test_ragged_fasta_is_refused(tmp_path):
         _build(fa, 50, 2)
     assert e.value.code == 51
     exe = os.path.join(hip.BIN_DIR, "homTable_setup")
-    r = subprocess.run([exe, fa, "50", helpers.split_path("phys", 1), str(tmp_path / "E"), str(tmp_path / "I"),
-                        helpers.split_path("par", 1), "BOTH", "2", "FULL"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    assert r.returncode == 51, r.stdout
+    ex, inx, r = helpers.run_tool(exe, fa, 50, 2, helpers.split_path("phys", 1), helpers.split_path("par", 1), str(tmp_path / "a"))
+    assert r.returncode == 0, r.stdout
+    ex2, inx2, r2 = helpers.run_tool(exe, good, 50, 2, helpers.split_path("phys", 1), helpers.split_path("par", 1), str(tmp_path / "b"))
+    assert r2.returncode == 0, r2.stdout
+    assert helpers.read(ex) == helpers.read(ex2) and helpers.read(inx) == helpers.read(inx2) and len(helpers.read(ex)) > 0
 
 
 @pytest.mark.parametrize("sharded", [False, True])
