@@ -193,6 +193,29 @@ def main():
                                    "ms_device": round(best["ms_total"], 3), "ms_wall_with_upload_and_allocation": round(wall, 3),
                                    "stage_ms": {k: round(best[k], 3) for k in ("ms_parse", "ms_lookups", "ms_hubs")},
                                    "image_bytes": int(best["device_bytes"]), "hub_positions": int(best["hub_positions"])}
+            # the reference-side file row: contig index of the same image, `cora faiGenerate` beside it
+            best = None
+            img_bytes = bytes(image)
+            for _ in range(3):
+                fa = hip.Fasta(img_bytes)
+                info = fa.info()
+                fai = fa.fai_text()
+                fa.close()
+                if best is None or info["ms_scan"] < best["ms_scan"]:
+                    best = info
+            fa_path = os.path.join(tmp, "bench.fa")
+            with open(fa_path, "wb") as f:
+                f.write(img_bytes)
+            fai_oracle = os.path.join(ROOT, "oracle", "fai_oracle")
+            cpu = None
+            if os.path.exists(fai_oracle):
+                tw = time.perf_counter()
+                r = subprocess.run([fai_oracle, fa_path], stdout=subprocess.PIPE)
+                cpu = {"ms": round((time.perf_counter() - tw) * 1e3, 1), "kind": "port", "cores": 1, "same_bytes": r.stdout == fai}
+            out["fasta_scan"] = {"what": "contig index (.fai bytes of cora faiGenerate, cora.cpp:1006-1029) of the bench image, image resident in HBM",
+                                 "ms_device": round(best["ms_scan"], 3), "image_bytes": int(best["image_bytes"]), "lines": int(best["lines"]),
+                                 "GB_per_s_algorithmic": round(2 * best["image_bytes"] / 1e6 / max(best["ms_scan"], 1e-6), 1),
+                                 "conforming": int(best["conforming"]), "cpu": cpu}
         print(json.dumps(out), flush=True)
     job.close()
     if world > 1:

@@ -173,7 +173,7 @@ def test_executables(tmp_path):
 def test_full_size_scan_equals_the_oracle(tmp_path):
     """The 64 Mbp bench reference: .fai bytes against the oracle, conforming layout recognised."""
     contigs = synth.workload_chr20_like()
-    image, _ = synth.fasta_image(contigs, 60)
+    image = synth.fasta_image(contigs, 60)[0]
     image = bytes(image)
     p = str(tmp_path / "big.fa")
     open(p, "wb").write(image)
