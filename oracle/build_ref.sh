@@ -25,3 +25,11 @@ if [ -f "$msrc" ]; then
   wait
   echo "built $here/_ref/ref_loader{,_L,_e3,_L_e3}"
 fi
+# collapse / collapse_L (read-side read-mer dedup): /root/reference/makefile:6-9 minus -march=native
+csrc="${CORA_REFERENCE:-/root/reference}/collapse.cpp"
+if [ -f "$csrc" ]; then
+  g++ -static -O3 -w -o "$here/_ref/collapse" "$csrc" 2>/dev/null &
+  g++ -DCHR_SHORT -static -O3 -w -o "$here/_ref/collapse_L" "$csrc" 2>/dev/null &
+  wait
+  echo "built $here/_ref/collapse and collapse_L"
+fi
