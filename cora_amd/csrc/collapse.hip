@@ -1,0 +1,802 @@
+// collapse.hip -- CORA's read-side read-mer collapsing on gfx950.
+// CL = /root/reference/collapse.cpp, whole-input run mode (argv[13] = NONE, the form cora.cpp:1674-1692 issues).
+//
+// What the reference does with one hash map (CL:640-643) is done here with sorts:
+//   * every N-free reference window of R bases (CL:656-711) and every read-mer of the input (reads, mates, splits in
+//     file order, CL:923-2171) becomes a record (FNV-1a 64 of its canonical form, id); ids order the records the way
+//     the reference inserts them: reference positions first (id = global position), then read-mers (id = G + index);
+//   * a stable radix sort on the hash brings equal read-mers together in insertion order; neighbours with equal hashes
+//     are compared base by base (different read-mers with one hash are re-ordered by a repair kernel);
+//   * a group's first record is the one the reference would have inserted: it decides "in the reference or not",
+//     position and stored direction (CL:686-695, 948-972); a read-mer's id digits are 2 * index + direction flag;
+//   * the reference prints in the iteration order of its tr1::unordered_map (CL:2305): bucket = hash mod B ascending,
+//     later insertions first inside a bucket.  A second sort on (bucket, ~id of the first record) gives that order;
+//   * three kernels size, place (scans) and write the text of the three output files.
+// The hash (tr1::hash<string> = FNV-1a 64) and B come from libstdc++ itself on the host (collapse_host.cpp).
+// Integer / byte work; the heavy parts are the sequential FNV over R bases per record (ALU) and the sorts (HBM).
+#include "job_internal.hpp"
+
+using namespace cora;
+
+namespace {
+
+constexpr int CT = 256;
+constexpr u64 FNV_BASIS = 14695981039346656037ull, FNV_PRIME = 1099511628211ull;
+constexpr u32 ACGT_PACKED = 0x54474341u;       // 'A' 'C' 'G' 'T' by 2-bit code
+
+struct Src {               // where read-mers live
+    const u64 *pk;         // 2-bit packed reference (kernels.hip: k_pack)
+    const u8 *rd;          // FASTQ images
+    const u64 *seq_at;     // [reads] byte offset of each read's sequence line
+    u64 G;                 // ids below G are reference positions; id - G = running read-mer index
+    u32 R, splits;
+};
+
+struct CollapseCounters {
+    unsigned long long bad_read_bytes, n_mixed, n_owners, n_lrn, name_overflow;
+};
+
+__device__ __forceinline__ u32 comp_char(u32 c)
+{
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == 'N' ? 'N' : 0u;
+}
+
+struct Item { u64 base; bool is_ref; };
+
+__device__ __forceinline__ Item locate(const Src &s, u32 id)
+{
+    Item it;
+    it.is_ref = id < s.G;
+    if (it.is_ref) it.base = id;
+    else { const u64 idx = (u64)id - s.G; it.base = s.seq_at[idx / s.splits] + (idx % s.splits) * s.R; }
+    return it;
+}
+
+__device__ __forceinline__ u32 fwd_char(const Src &s, const Item &it, u32 i)
+{
+    if (it.is_ref) {
+        const u64 g = it.base + i;
+        const u32 code = (u32)(s.pk[g >> 5] >> (62 - 2 * (g & 31))) & 3u;
+        return (ACGT_PACKED >> (8 * code)) & 0xFFu;
+    }
+    return s.rd[it.base + i];
+}
+
+// CL:97-122: 1 iff the reverse complement is the lexicographically smaller one
+__device__ __forceinline__ u32 strand_of(const Src &s, const Item &it)
+{
+    for (u32 i = 0; i < s.R; i++) {
+        const u32 a = fwd_char(s, it, i), b = comp_char(fwd_char(s, it, s.R - 1 - i));
+        if (a < b) return 0;
+        if (a > b) return 1;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ u32 canon_char(const Src &s, const Item &it, u32 sw, u32 i)
+{
+    return sw ? comp_char(fwd_char(s, it, s.R - 1 - i)) : fwd_char(s, it, i);
+}
+
+// <0, 0, >0: canonical read-mer of a against that of b
+__device__ int seq_cmp(const Src &s, u32 ida, u32 idb)
+{
+    const Item a = locate(s, ida), b = locate(s, idb);
+    const u32 sa = strand_of(s, a), sb = strand_of(s, b);
+    for (u32 i = 0; i < s.R; i++) {
+        const u32 x = canon_char(s, a, sa, i), y = canon_char(s, b, sb, i);
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *lds, u32 *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[wv] = x;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CT / 64; w++) { u32 t = lds[w]; if (w < wv) base += t; tot += t; }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+// ------------------------------------------------------------------ FASTQ: sequence line of every record
+__global__ __launch_bounds__(CT) void k_nl_count(const u8 *__restrict__ img, u64 n, u32 *__restrict__ blk)
+{
+    __shared__ u32 lds[4];
+    const u64 at = ((u64)blockIdx.x * CT + threadIdx.x) * 16;
+    u32 c = 0;
+    if (at < n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(img + at);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) c += (at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n';
+    }
+    u32 tot;
+    block_excl_scan(c, lds, &tot);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+// newline number j of the file (0-based) with j % 4 == 0 ends a header line: the sequence of record j / 4 starts behind it
+__global__ __launch_bounds__(CT) void k_fq_emit(const u8 *__restrict__ img, u64 n, const u64 *__restrict__ blk_off, u64 file_off,
+                                                u64 *__restrict__ seq_at, u64 first_read, u32 stride, u64 n_records)
+{
+    __shared__ u32 lds[4];
+    const u64 at = ((u64)blockIdx.x * CT + threadIdx.x) * 16;
+    u32 c = 0;
+    u32 w[4] = {0, 0, 0, 0};
+    if (at < n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(img + at);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+#pragma unroll
+        for (int i = 0; i < 16; i++) c += (at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n';
+    }
+    u64 j = blk_off[blockIdx.x] + block_excl_scan(c, lds, nullptr);
+    if (!c) return;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if ((at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n') {
+            if ((j & 3) == 0 && (j >> 2) < n_records) seq_at[(first_read + (j >> 2)) * stride] = file_off + at + i + 1;
+            j++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ reference windows
+__global__ __launch_bounds__(CT) void k_win_count(u64 G, u32 R, const u32 *__restrict__ bad, u32 *__restrict__ blk, u32 *__restrict__ wvalid)
+{
+    __shared__ u32 wsum[4];
+    const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
+    bool ok = g + R <= G;
+    u64 p = g;
+    u32 left = R;
+    while (ok && left) {
+        const u32 o = (u32)(p & 31), n = min(32u - o, left);
+        const u32 mask = (n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1u) << (32 - o - n));
+        if (bad[p >> 5] & mask) ok = false;
+        p += n; left -= n;
+    }
+    const u64 bal = __ballot(ok);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
+    if (lane == 0 || lane == 32) wvalid[g >> 5] = __brev((u32)(bal >> lane));
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(CT) void k_win_emit(Src s, const u32 *__restrict__ wvalid, const u64 *__restrict__ blk_off,
+                                                 u64 *__restrict__ key, u32 *__restrict__ id)
+{
+    __shared__ u32 lds[4];
+    const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
+    const bool ok = g < s.G && ((wvalid[g >> 5] >> (31 - (u32)(g & 31))) & 1u);
+    const u32 r = block_excl_scan(ok ? 1u : 0u, lds, nullptr);
+    if (!ok) return;
+    Item it; it.base = g; it.is_ref = true;
+    const u32 sw = strand_of(s, it);
+    u64 h = FNV_BASIS;
+    if (!sw) {
+        u64 q = g, w = s.pk[q >> 5];
+        for (u32 i = 0; i < s.R; i++, q++) {
+            if ((q & 31) == 0) w = s.pk[q >> 5];
+            const u32 code = (u32)(w >> (62 - 2 * (q & 31))) & 3u;
+            h = (h ^ ((ACGT_PACKED >> (8 * code)) & 0xFFu)) * FNV_PRIME;
+        }
+    } else {
+        u64 q = g + s.R - 1, w = s.pk[q >> 5];
+        for (u32 i = 0; i < s.R; i++, q--) {
+            if ((q & 31) == 31) w = s.pk[q >> 5];
+            const u32 code = 3u - ((u32)(w >> (62 - 2 * (q & 31))) & 3u);
+            h = (h ^ ((ACGT_PACKED >> (8 * code)) & 0xFFu)) * FNV_PRIME;
+        }
+    }
+    const u64 at = blk_off[blockIdx.x] + r;
+    key[at] = h; id[at] = (u32)g;
+}
+
+// ------------------------------------------------------------------ read-mers of the input
+__global__ __launch_bounds__(CT) void k_read_keys(Src s, u64 n_items, u64 out_base, u64 *__restrict__ key, u32 *__restrict__ id,
+                                                  CollapseCounters *ctr)
+{
+    const u64 idx = (u64)blockIdx.x * CT + threadIdx.x;
+    if (idx >= n_items) return;
+    Item it;
+    it.is_ref = false;
+    it.base = s.seq_at[idx / s.splits] + (idx % s.splits) * s.R;
+    const u8 *p = s.rd + it.base;
+    u32 sw = 0, bad = 0;
+    for (u32 i = 0; i < s.R; i++) {
+        const u32 a = p[i], b = comp_char(p[s.R - 1 - i]);
+        if (a < b) break;
+        if (a > b) { sw = 1; break; }
+    }
+    u64 h = FNV_BASIS;
+    if (!sw) for (u32 i = 0; i < s.R; i++) { const u32 c = p[i]; bad += comp_char(c) == 0; h = (h ^ c) * FNV_PRIME; }
+    else for (u32 i = 0; i < s.R; i++) { const u32 c = comp_char(p[s.R - 1 - i]); bad += c == 0; h = (h ^ c) * FNV_PRIME; }
+    if (bad) atomicAdd(&ctr->bad_read_bytes, (unsigned long long)bad);
+    key[out_base + idx] = h; id[out_base + idx] = (u32)(s.G + idx);
+}
+
+// ------------------------------------------------------------------ groups of equal read-mers
+// head: 1 = first record of a group; 2 = same hash as the record before but another read-mer (repaired below)
+__global__ __launch_bounds__(CT) void k_heads(Src s, const u64 *__restrict__ key, const u32 *__restrict__ id, u64 n, u64 mask,
+                                              u32 *__restrict__ head, CollapseCounters *ctr)
+{
+    const u64 i = (u64)blockIdx.x * CT + threadIdx.x;
+    if (i >= n) return;
+    u32 h = 1;
+    if (i > 0 && ((key[i] ^ key[i - 1]) & mask) == 0) {
+        h = seq_cmp(s, id[i], id[i - 1]) == 0 ? 0u : 2u;
+        if (h == 2) atomicAdd(&ctr->n_mixed, 1ull);
+    }
+    head[i] = h;
+}
+
+// the first marked record of an equal-hash run owns the run's repair
+__global__ __launch_bounds__(CT) void k_mixed_owners(const u64 *__restrict__ key, const u32 *__restrict__ head, u64 n, u64 mask,
+                                                     u32 *__restrict__ owners, CollapseCounters *ctr)
+{
+    const u64 i = (u64)blockIdx.x * CT + threadIdx.x;
+    if (i >= n || head[i] != 2) return;
+    for (u64 q = i; q > 0 && ((key[q] ^ key[q - 1]) & mask) == 0; q--)
+        if (q < i && head[q] == 2) return;
+    owners[atomicAdd(&ctr->n_owners, 1ull)] = (u32)i;
+}
+
+// one thread per run: stable insertion sort of the run's ids by read-mer, then the group heads inside the run
+__global__ __launch_bounds__(64) void k_mixed_fix(Src s, u64 *__restrict__ key, u32 *__restrict__ id, u64 n, u64 mask,
+                                                  u32 *__restrict__ head, const u32 *__restrict__ owners, u64 n_owners)
+{
+    const u64 t = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (t >= n_owners) return;
+    u64 st = owners[t], en = st + 1;
+    while (st > 0 && ((key[st] ^ key[st - 1]) & mask) == 0) st--;
+    while (en < n && ((key[en] ^ key[en - 1]) & mask) == 0) en++;
+    for (u64 a = st + 1; a < en; a++) {
+        const u32 x = id[a];
+        const u64 kx = key[a];                  // the full hashes differ inside a run when the sort looked at fewer bits
+        u64 b = a;
+        while (b > st && seq_cmp(s, x, id[b - 1]) < 0) { id[b] = id[b - 1]; key[b] = key[b - 1]; b--; }
+        id[b] = x; key[b] = kx;
+    }
+    for (u64 q = st + 1; q < en; q++) head[q] = seq_cmp(s, id[q], id[q - 1]) == 0 ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(CT) void k_group_starts(const u32 *__restrict__ head, const u64 *__restrict__ gex, u64 n, u32 *__restrict__ gstart,
+                                                     u64 n_groups)
+{
+    const u64 i = (u64)blockIdx.x * CT + threadIdx.x;
+    if (i == 0) gstart[n_groups] = (u32)n;
+    if (i < n && head[i]) gstart[gex[i]] = (u32)i;
+}
+
+__device__ __forceinline__ u32 first_read_of(const u32 *__restrict__ id, u32 st, u32 en, u64 G)
+{
+    u32 lo = st, hi = en;
+    while (lo < hi) { const u32 mid = lo + (hi - lo) / 2; if (id[mid] < G) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// groups that hold at least one read-mer of the input are printed (CL:2311-2314)
+__global__ __launch_bounds__(CT) void k_group_flags(const u32 *__restrict__ id, const u32 *__restrict__ gstart, u64 n_groups, u64 G,
+                                                    u32 *__restrict__ flag)
+{
+    const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
+    if (g >= n_groups) return;
+    const u32 st = gstart[g], en = gstart[g + 1];
+    flag[g] = first_read_of(id, st, en, G) < en;
+}
+
+__global__ __launch_bounds__(CT) void k_group_emit(const u64 *__restrict__ key, const u32 *__restrict__ id, const u32 *__restrict__ gstart,
+                                                   const u32 *__restrict__ flag, const u64 *__restrict__ oex, u64 n_groups, u64 B,
+                                                   u64 *__restrict__ okey, u32 *__restrict__ oval)
+{
+    const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
+    if (g >= n_groups || !flag[g]) return;
+    const u32 st = gstart[g];
+    const u64 o = oex[g];
+    okey[o] = ((key[st] % B) << 32) | (u64)(0xFFFFFFFFu - id[st]);     // bucket ascending, later insertions first
+    oval[o] = (u32)g;
+}
+
+// ------------------------------------------------------------------ text of the three files
+struct OutParams {
+    u32 D, mapper, n_contigs;      // mapper: 0 GENERIC, 1 BWA, 2 BWA_MEM, 3 BOWTIE_2
+    u64 lrn_offset;
+    const u64 *ctg_gstart;
+};
+
+__device__ __forceinline__ u32 dec_digits(u64 v) { u32 n = 1; while (v >= 10) { v /= 10; n++; } return n; }
+__device__ __forceinline__ u32 put_dec(u8 *dst, u64 v)
+{
+    const u32 n = dec_digits(v);
+    for (u32 k = n; k-- > 0;) { dst[k] = (u8)('0' + v % 10); v /= 10; }
+    return n;
+}
+
+// id digits of the read-mer at sorted position q of a group whose first record is `first` (CL:948-972, 276-289, 491-506)
+__device__ __forceinline__ u64 id_value(const Src &s, const u32 *__restrict__ id, u32 q, bool in_ref, u32 ref_dir)
+{
+    const u32 x = id[q];
+    const u32 sw = strand_of(s, locate(s, x));
+    return 2 * ((u64)x - s.G) + (in_ref ? (sw != ref_dir) : sw);
+}
+
+__device__ __forceinline__ u32 lrn_len(u64 number, u32 D)
+{
+    const u32 n = dec_digits(number);
+    return n + 2 + ((n + 2) % D == 0 ? 1u : 0u);                        // CL:312-326
+}
+
+__global__ __launch_bounds__(CT) void k_out_flags(Src s, OutParams op, const u32 *__restrict__ id, const u32 *__restrict__ gstart,
+                                                  const u32 *__restrict__ oval, u64 m, u32 *__restrict__ lrn_flag, CollapseCounters *ctr)
+{
+    const u64 j = (u64)blockIdx.x * CT + threadIdx.x;
+    if (j >= m) return;
+    const u32 g = oval[j], st = gstart[g], en = gstart[g + 1];
+    const bool in_ref = id[st] < s.G;
+    u32 lrn = 0;
+    if (!in_ref) {
+        const u64 name_len = (u64)op.D * (en - st);
+        if (name_len > 0xF0000000ull) atomicAdd(&ctr->name_overflow, 1ull);
+        if (op.mapper == 0 || op.mapper == 3) lrn = name_len > 194;                                    // CL:2321, 2381
+        else {
+            const u64 v = id_value(s, id, en - 1, false, 0);
+            const u32 c2 = (u32)(v % 94) + 33, c1 = (u32)((v / 94) % 94) + 33;                         // D >= 2
+            lrn = name_len > 5000000 || (c1 == '/' && (op.mapper == 1 ? (c2 == '1' || c2 == '2') : (c2 >= '0' && c2 <= '9')));   // CL:2339-2342, 2360-2363
+        }
+    }
+    lrn_flag[j] = lrn;
+}
+
+__device__ __forceinline__ void ref_place(const OutParams &op, u64 g, u32 &code, u32 &pos)
+{
+    u32 lo = 0, hi = op.n_contigs;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (op.ctg_gstart[mid] <= g) lo = mid; else hi = mid; }
+    code = lo + 1; pos = (u32)(g - op.ctg_gstart[lo]) + 1;
+}
+
+__global__ __launch_bounds__(CT) void k_out_sizes(Src s, OutParams op, const u32 *__restrict__ id, const u32 *__restrict__ gstart,
+                                                  const u32 *__restrict__ oval, u64 m, const u32 *__restrict__ lrn_flag,
+                                                  const u64 *__restrict__ lrn_rank, u32 *__restrict__ sz_r, u32 *__restrict__ sz_p,
+                                                  u32 *__restrict__ sz_l)
+{
+    const u64 j = (u64)blockIdx.x * CT + threadIdx.x;
+    if (j >= m) return;
+    const u32 g = oval[j], st = gstart[g], en = gstart[g + 1];
+    const bool in_ref = id[st] < s.G;
+    const u32 fr = first_read_of(id, st, en, s.G);
+    const u32 name_len = op.D * (en - fr);
+    u32 r = 0, p = 0, l = 0;
+    if (in_ref) {
+        u32 code, pos;
+        ref_place(op, id[st], code, pos);
+        p = name_len + 1 + dec_digits(code) + 1 + dec_digits(pos) + 1 + dec_digits(s.R) + 1;          // CL:2400-2401
+    } else {
+        u32 shown = name_len;
+        if (lrn_flag[j]) { shown = lrn_len(op.lrn_offset + lrn_rank[j] + 1, op.D); l = shown + 1 + name_len + 1; }
+        r = 1 + shown + 1 + s.R + 1 + (op.mapper == 3 ? 2 + s.R + 1 : 0);
+    }
+    sz_r[j] = r; sz_p[j] = p; sz_l[j] = l;
+}
+
+__device__ __forceinline__ void put_name(const Src &s, u32 D, const u32 *__restrict__ id, u32 fr, u32 en, bool in_ref, u32 ref_dir, u8 *dst)
+{
+    for (u32 q = fr; q < en; q++, dst += D) {
+        u64 v = id_value(s, id, q, in_ref, ref_dir);
+        for (u32 k = D; k-- > 0;) { dst[k] = (u8)(v % 94 + 33); v /= 94; }
+    }
+}
+
+__global__ __launch_bounds__(CT) void k_out_write(Src s, OutParams op, const u32 *__restrict__ id, const u32 *__restrict__ gstart,
+                                                  const u32 *__restrict__ oval, u64 m, const u32 *__restrict__ lrn_flag,
+                                                  const u64 *__restrict__ lrn_rank, const u64 *__restrict__ off_r,
+                                                  const u64 *__restrict__ off_p, const u64 *__restrict__ off_l, u8 *__restrict__ out_r,
+                                                  u8 *__restrict__ out_p, u8 *__restrict__ out_l)
+{
+    const u64 j = (u64)blockIdx.x * CT + threadIdx.x;
+    if (j >= m) return;
+    const u32 g = oval[j], st = gstart[g], en = gstart[g + 1];
+    const u32 first = id[st];
+    const bool in_ref = first < s.G;
+    const u32 fr = first_read_of(id, st, en, s.G);
+    const u32 name_len = op.D * (en - fr);
+    const Item head = locate(s, first);
+    const u32 head_sw = strand_of(s, head);
+    if (in_ref) {
+        u8 *w = out_p + off_p[j];
+        put_name(s, op.D, id, fr, en, true, head_sw, w);
+        w += name_len;
+        u32 code, pos;
+        ref_place(op, first, code, pos);
+        *w++ = '\t'; w += put_dec(w, code);
+        *w++ = '\t'; w += put_dec(w, pos);
+        *w++ = '\t'; w += put_dec(w, s.R);
+        *w = '\n';
+        return;
+    }
+    u8 *w = out_r + off_r[j];
+    *w++ = op.mapper == 3 ? '@' : '>';
+    if (lrn_flag[j]) {
+        u8 *l = out_l + off_l[j];
+        const u64 number = op.lrn_offset + lrn_rank[j] + 1;
+        const u32 n = dec_digits(number), extra = (n + 2) % op.D == 0;
+        for (int copy = 0; copy < 2; copy++) {
+            u8 *c = copy ? l : w;
+            *c++ = '#'; c += put_dec(c, number); *c++ = '#';
+            if (extra) *c++ = '#';
+            if (copy) l = c; else w = c;
+        }
+        *l++ = '\t';
+        put_name(s, op.D, id, fr, en, false, 0, l);
+        l[name_len] = '\n';
+    } else {
+        put_name(s, op.D, id, fr, en, false, 0, w);
+        w += name_len;
+    }
+    *w++ = '\n';
+    for (u32 i = 0; i < s.R; i++) w[i] = (u8)canon_char(s, head, head_sw, i);
+    w += s.R;
+    *w++ = '\n';
+    if (op.mapper == 3) {                                                                              // CL:2394-2395
+        *w++ = '+'; *w++ = '\n';
+        for (u32 i = 0; i < s.R; i++) w[i] = 'S';
+        w[s.R] = '\n';
+    }
+}
+
+u32 grid_of(u64 n, u32 per) { const u64 g = (n + per - 1) / per; return (u32)(g ? g : 1); }
+
+}  // namespace
+
+struct cora_hip_collapse {
+    cora_hip_collapse_params prm;
+    u32 R = 0;
+    u64 B = 0, first_rehash_at = 0;
+    hipStream_t stream = nullptr;
+    cora_hip_job *ref_job = nullptr;          // holds the packed reference (pk, bad, contig table)
+    std::vector<u8> h_rd;                     // FASTQ images, 16-byte aligned starts
+    struct File { u64 off, bytes; };
+    std::vector<File> files;                  // in list order: sample 0 mate 1, sample 0 mate 2, ...
+    HBuf<u8> out_r, out_p, out_l;
+    u64 n_r = 0, n_p = 0, n_l = 0;
+    SortScratch sort_scratch;
+    cora_hip_collapse_stats st;
+    ~cora_hip_collapse()
+    {
+        sort_scratch.release();
+        if (ref_job) cora_hip_job_destroy(ref_job);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int scan_u32(hipStream_t s, const u32 *in, u64 *out, u64 n, u64 *total_dev)
+{
+    DBuf<u64> tmp;
+    RCQ(tmp.alloc(scan_scratch_elems(n)));
+    if (exclusive_scan_u32_to_u64(s, in, out, n, tmp.p, total_dev)) return fail(100, "scan launch failed");
+    HIPQ(hipStreamSynchronize(s));            // tmp is released on return
+    return 0;
+}
+
+int run_impl(cora_hip_collapse *c)
+{
+    hipStream_t s = c->stream;
+    const cora_hip_collapse_params &prm = c->prm;
+    cora_hip_collapse_stats &st = c->st;
+    memset(&st, 0, sizeof st);
+    const u32 R = c->R, splits = (u32)prm.splits;
+    const auto t_begin = std::chrono::steady_clock::now();
+    hipEvent_t ev[6];
+    for (auto &e : ev) HIPQ(hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 6; i++) (void)hipEventDestroy(e[i]); } } guard{ev};
+
+    DBuf<CollapseCounters> ctr;
+    DBuf<u64> tot;
+    RCQ(ctr.alloc(1)); RCQ(tot.alloc(4));
+    HIPQ(hipMemsetAsync(ctr.p, 0, sizeof(CollapseCounters), s));
+
+    // ---- the reads: images to HBM, sequence line of every record ----
+    const u32 stride = prm.paired ? 2u : 1u;
+    if (c->files.size() % stride) return fail(6, "paired input needs two files per sample");
+    DBuf<u8> rd;
+    RCQ(rd.alloc(c->h_rd.size() + 1024));
+    if (!c->h_rd.empty()) HIPQ(hipMemcpyAsync(rd.p, c->h_rd.data(), c->h_rd.size(), hipMemcpyHostToDevice, s));
+    HIPQ(hipEventRecord(ev[0], s));
+    std::vector<u64> file_records(c->files.size());
+    std::vector<DBuf<u64> *> blk_offs;
+    u64 n_reads = 0;                                        // records over all samples (pairs count once here)
+    struct Guard { std::vector<DBuf<u64> *> &v; ~Guard() { for (auto *p : v) delete p; } } g2{blk_offs};
+    for (size_t f = 0; f < c->files.size(); f++) {
+        const auto &fl = c->files[f];
+        const u32 blocks = grid_of(fl.bytes, CT * 16);
+        DBuf<u32> blk;
+        RCQ(blk.alloc(blocks));
+        DBuf<u64> *bo = new DBuf<u64>();
+        blk_offs.push_back(bo);
+        RCQ(bo->alloc(blocks));
+        hipLaunchKernelGGL(k_nl_count, dim3(blocks), dim3(CT), 0, s, rd.p + fl.off, fl.bytes, blk.p);
+        RCQ(scan_u32(s, blk.p, bo->p, blocks, tot.p));
+        u64 n_nl = 0;
+        HIPQ(hipMemcpyAsync(&n_nl, tot.p, 8, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        const u64 lines = n_nl + ((fl.bytes && c->h_rd[fl.off + fl.bytes - 1] != '\n') ? 1 : 0);
+        if (lines % 4) return fail(7, "input file %zu holds %llu lines: not a multiple of 4 (FASTQ records are read 4 lines at a time, CL:923-935)", f + 1, (unsigned long long)lines);
+        file_records[f] = lines / 4;
+        if (prm.paired && (f & 1) && file_records[f] != file_records[f - 1])
+            return fail(7, "mate files of sample %zu hold %llu and %llu records", f / 2 + 1, (unsigned long long)file_records[f - 1], (unsigned long long)file_records[f]);
+        if (!prm.paired || (f & 1)) n_reads += file_records[f];
+    }
+    const u64 n_rd = n_reads * stride;                      // sequence lines
+    const u64 n_items = n_rd * splits;
+    DBuf<u64> seq_at;
+    RCQ(seq_at.alloc(n_rd + 1));
+    {
+        u64 first = 0;
+        for (size_t f = 0; f < c->files.size(); f++) {
+            const auto &fl = c->files[f];
+            const u32 mate = prm.paired ? (u32)(f & 1) : 0u;
+            hipLaunchKernelGGL(k_fq_emit, dim3(grid_of(fl.bytes, CT * 16)), dim3(CT), 0, s, rd.p + fl.off, fl.bytes, blk_offs[f]->p, fl.off,
+                               seq_at.p + mate, first, stride, file_records[f]);
+            if (!prm.paired || (f & 1)) first += file_records[f];
+        }
+    }
+
+    // ---- the reference: packed by the table builder's kernel ----
+    u64 G = 0, NW = 0, other_letters = 0;
+    DevParams dp;
+    memset(&dp, 0, sizeof dp);
+    DBuf<u32> wvalid, wblk;
+    DBuf<u64> woff;
+    cora_hip_job *rj = c->ref_job;
+    if (rj) {
+        PoolScope no_pool(nullptr);
+        RCQ(st_pack(rj));
+        DevCounters h;
+        RCQ(read_counters(rj, h));
+        FORMAT_ERROR_CHECK(h);
+        other_letters = h.other_letters;
+        dp = rj->dp;
+        G = dp.G;
+        const u32 wb = grid_of(G, CT);
+        RCQ(wvalid.alloc((u64)wb * CT / 32 + 4)); RCQ(wblk.alloc(wb)); RCQ(woff.alloc(wb));
+        hipLaunchKernelGGL(k_win_count, dim3(wb), dim3(CT), 0, s, G, R, rj->bad.p, wblk.p, wvalid.p);
+        RCQ(scan_u32(s, wblk.p, woff.p, wb, tot.p));
+        HIPQ(hipMemcpyAsync(&NW, tot.p, 8, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+    }
+    if (G + n_items >= 0xFFFFFFFFull) return fail(19, "reference positions + read-mers = %llu: 32-bit record ids do not hold that", (unsigned long long)(G + n_items));
+    { u64 lim = 1; for (int i = 0; i < prm.digit_len; i++) lim *= 94;
+      if (n_items && 2 * n_items - 1 >= lim) return fail(19, "digit length %d cannot number %llu read-mers", prm.digit_len, (unsigned long long)n_items); }
+    const u64 N = NW + n_items;
+    st.ref_windows = NW; st.read_mers = n_items; st.reads = n_rd;
+    HIPQ(hipEventRecord(ev[1], s));
+
+    // ---- records ----
+    Src src;
+    src.pk = rj ? rj->pk.p : nullptr; src.rd = rd.p; src.seq_at = seq_at.p; src.G = G; src.R = R; src.splits = splits;
+    DBuf<u64> key, tkey;
+    DBuf<u32> id, tid;
+    RCQ(key.alloc(N + 1)); RCQ(tkey.alloc(N + 1)); RCQ(id.alloc(N + 1)); RCQ(tid.alloc(N + 1));
+    if (rj && G) hipLaunchKernelGGL(k_win_emit, dim3(grid_of(G, CT)), dim3(CT), 0, s, src, wvalid.p, woff.p, key.p, id.p);
+    if (n_items) hipLaunchKernelGGL(k_read_keys, dim3(grid_of(n_items, CT)), dim3(CT), 0, s, src, n_items, NW, key.p, id.p, ctr.p);
+    CollapseCounters hc;
+    HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
+    HIPQ(hipStreamSynchronize(s));
+    if (hc.bad_read_bytes)
+        return fail(78, "%llu read bytes are outside A C G T N or a sequence line is shorter than %u (the reference would cut such keys at a NUL, CL:86-122)",
+                    (unsigned long long)hc.bad_read_bytes, R * splits);
+    wvalid.release(); wblk.release(); woff.release();
+    HIPQ(hipEventRecord(ev[2], s));
+
+    // ---- equal read-mers side by side, in insertion order ----
+    int hash_bits = 64;
+    if (const char *e = getenv("CORA_COLLAPSE_HASH_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 64) hash_bits = v & ~7; }
+    const u64 mask = hash_bits == 64 ? ~0ull : ((1ull << hash_bits) - 1);
+    SortArrays ka, kt;
+    ka.a = key.p; ka.c = id.p; kt.a = tkey.p; kt.c = tid.p;
+    SortTiming timing;
+    if (N && radix_sort(s, ka, kt, N, 0, hash_bits, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
+    u64 *skey = ka.a;
+    u32 *sid = ka.c;
+    DBuf<u32> head;
+    RCQ(head.alloc(N + 1));
+    if (N) hipLaunchKernelGGL(k_heads, dim3(grid_of(N, CT)), dim3(CT), 0, s, src, skey, sid, N, mask, head.p, ctr.p);
+    HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
+    HIPQ(hipStreamSynchronize(s));
+    st.hash_collisions = hc.n_mixed;
+    if (hc.n_mixed) {
+        DBuf<u32> owners;
+        RCQ(owners.alloc(hc.n_mixed));
+        hipLaunchKernelGGL(k_mixed_owners, dim3(grid_of(N, CT)), dim3(CT), 0, s, skey, head.p, N, mask, owners.p, ctr.p);
+        HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(k_mixed_fix, dim3(grid_of(hc.n_owners, 64)), dim3(64), 0, s, src, skey, sid, N, mask, head.p, owners.p, (u64)hc.n_owners);
+        HIPQ(hipStreamSynchronize(s));
+    }
+    u64 n_groups = 0;
+    DBuf<u64> gex;
+    DBuf<u32> gstart;
+    RCQ(gex.alloc(N + 1));
+    if (N) {
+        RCQ(scan_u32(s, head.p, gex.p, N, tot.p));
+        HIPQ(hipMemcpyAsync(&n_groups, tot.p, 8, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+    }
+    st.distinct = n_groups;
+    // the reference's table re-buckets itself with its first_rehash_at-th element; the order after that is not reproduced
+    // (windows with letters other than A C G T N enter its table under cut keys: counted here as one element each, an upper bound)
+    const u64 garbage_bound = other_letters * R;
+    if (n_groups + garbage_bound + 1 >= c->first_rehash_at)
+        return fail(77, "%llu distinct read-mers (+ %llu reference windows with other letters): the reference's hash map re-buckets itself at %llu "
+                        "elements and its output order beyond that point is not reproduced", (unsigned long long)n_groups,
+                    (unsigned long long)garbage_bound, (unsigned long long)c->first_rehash_at);
+    RCQ(gstart.alloc(n_groups + 1));
+    hipLaunchKernelGGL(k_group_starts, dim3(grid_of(N, CT)), dim3(CT), 0, s, head.p, gex.p, N, gstart.p, n_groups);
+    head.release(); gex.release();
+    HIPQ(hipEventRecord(ev[3], s));
+
+    // ---- printed groups in the hash map's iteration order ----
+    u64 M = 0;
+    DBuf<u32> gflag;
+    DBuf<u64> oex;
+    RCQ(gflag.alloc(n_groups + 1)); RCQ(oex.alloc(n_groups + 1));
+    if (n_groups) {
+        hipLaunchKernelGGL(k_group_flags, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, sid, gstart.p, n_groups, G, gflag.p);
+        RCQ(scan_u32(s, gflag.p, oex.p, n_groups, tot.p));
+        HIPQ(hipMemcpyAsync(&M, tot.p, 8, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+    }
+    st.printed = M;
+    DBuf<u64> okey, tokey;
+    DBuf<u32> oval, toval;
+    RCQ(okey.alloc(M + 1)); RCQ(tokey.alloc(M + 1)); RCQ(oval.alloc(M + 1)); RCQ(toval.alloc(M + 1));
+    if (M) hipLaunchKernelGGL(k_group_emit, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, skey, sid, gstart.p, gflag.p, oex.p, n_groups, c->B, okey.p, oval.p);
+    gflag.release(); oex.release();
+    SortArrays oa, ot;
+    oa.a = okey.p; oa.c = oval.p; ot.a = tokey.p; ot.c = toval.p;
+    int bucket_bits = 1;
+    while ((1ull << bucket_bits) < c->B) bucket_bits++;
+    if (M && radix_sort(s, oa, ot, M, 0, 32 + bucket_bits, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
+    const u32 *ord = oa.c;
+    HIPQ(hipEventRecord(ev[4], s));
+
+    // ---- sizes, places, bytes ----
+    OutParams op;
+    op.D = (u32)prm.digit_len; op.mapper = (u32)prm.mapper; op.n_contigs = dp.n_contigs; op.lrn_offset = prm.lrn_offset; op.ctg_gstart = dp.ctg_gstart;
+    DBuf<u32> lrn_flag, sz_r, sz_p, sz_l;
+    DBuf<u64> lrn_rank, off_r, off_p, off_l;
+    RCQ(lrn_flag.alloc(M + 1)); RCQ(sz_r.alloc(M + 1)); RCQ(sz_p.alloc(M + 1)); RCQ(sz_l.alloc(M + 1));
+    RCQ(lrn_rank.alloc(M + 1)); RCQ(off_r.alloc(M + 1)); RCQ(off_p.alloc(M + 1)); RCQ(off_l.alloc(M + 1));
+    u64 totals[4] = {0, 0, 0, 0};
+    c->n_r = c->n_p = c->n_l = 0;
+    if (M) {
+        const u32 gb = grid_of(M, CT);
+        hipLaunchKernelGGL(k_out_flags, dim3(gb), dim3(CT), 0, s, src, op, sid, gstart.p, ord, M, lrn_flag.p, ctr.p);
+        RCQ(scan_u32(s, lrn_flag.p, lrn_rank.p, M, tot.p + 3));
+        hipLaunchKernelGGL(k_out_sizes, dim3(gb), dim3(CT), 0, s, src, op, sid, gstart.p, ord, M, lrn_flag.p, lrn_rank.p, sz_r.p, sz_p.p, sz_l.p);
+        RCQ(scan_u32(s, sz_r.p, off_r.p, M, tot.p));
+        RCQ(scan_u32(s, sz_p.p, off_p.p, M, tot.p + 1));
+        RCQ(scan_u32(s, sz_l.p, off_l.p, M, tot.p + 2));
+        HIPQ(hipMemcpyAsync(totals, tot.p, 32, hipMemcpyDeviceToHost, s));
+        HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        if (hc.name_overflow) return fail(19, "a read-mer's name exceeds 4 GiB");
+        DBuf<u8> d_r, d_p, d_l;
+        RCQ(d_r.alloc(totals[0] + 16)); RCQ(d_p.alloc(totals[1] + 16)); RCQ(d_l.alloc(totals[2] + 16));
+        hipLaunchKernelGGL(k_out_write, dim3(gb), dim3(CT), 0, s, src, op, sid, gstart.p, ord, M, lrn_flag.p, lrn_rank.p, off_r.p, off_p.p, off_l.p,
+                           d_r.p, d_p.p, d_l.p);
+        HIPQ(hipEventRecord(ev[5], s));
+        RCQ(c->out_r.reserve(totals[0] + 1)); RCQ(c->out_p.reserve(totals[1] + 1)); RCQ(c->out_l.reserve(totals[2] + 1));
+        if (totals[0]) HIPQ(hipMemcpyAsync(c->out_r.p, d_r.p, totals[0], hipMemcpyDeviceToHost, s));
+        if (totals[1]) HIPQ(hipMemcpyAsync(c->out_p.p, d_p.p, totals[1], hipMemcpyDeviceToHost, s));
+        if (totals[2]) HIPQ(hipMemcpyAsync(c->out_l.p, d_l.p, totals[2], hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        c->n_r = totals[0]; c->n_p = totals[1]; c->n_l = totals[2];
+    } else {
+        HIPQ(hipEventRecord(ev[5], s));
+        HIPQ(hipStreamSynchronize(s));
+    }
+    st.lrn_names = totals[3];
+    st.reads_bytes = c->n_r; st.perfect_bytes = c->n_p; st.lrn_bytes = c->n_l;
+    HIPQ(hipEventElapsedTime(&st.ms_parse, ev[0], ev[1]));
+    HIPQ(hipEventElapsedTime(&st.ms_keys, ev[1], ev[2]));
+    HIPQ(hipEventElapsedTime(&st.ms_group, ev[2], ev[3]));
+    HIPQ(hipEventElapsedTime(&st.ms_order, ev[3], ev[4]));
+    HIPQ(hipEventElapsedTime(&st.ms_text, ev[4], ev[5]));
+    HIPQ(hipEventElapsedTime(&st.ms_device, ev[0], ev[5]));
+    st.ms_sort_scatter = timing.scatter_ms; st.n_sort_scatter = timing.scatter_launches; st.sort_scatter_bytes = timing.scatter_bytes;
+    st.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cora_hip_collapse_create(const cora_hip_collapse_params *p, cora_hip_collapse **out)
+{
+    if (!p || !out) return fail(10, "null argument");
+    if (g_device < 0) return fail(102, "cora_hip_init has not succeeded");
+    if (p->splits < 1 || p->splits > 3) return fail(9, "Split mode unrecognized");                     // CL:584-588
+    if (p->mapper < 0 || p->mapper > 3) return fail(19, "mapper mode out of range");
+    if (p->digit_len < 2 || p->digit_len > 10) return fail(19, "digit length %d outside 2..10 (CL:32)", p->digit_len);
+    if (p->read_len < p->splits || p->read_len >= 300) return fail(19, "read length %d outside %d..299 (CL:27)", p->read_len, p->splits);
+    cora_hip_collapse *c = new cora_hip_collapse();
+    c->prm = *p;
+    c->R = (u32)(p->read_len / p->splits);                                                              // CL:566-583
+    if (cora_hip_collapse_table_geometry(&c->B, &c->first_rehash_at) || c->B < 2) { delete c; return fail(19, "cannot determine the hash table geometry"); }
+    memset(&c->st, 0, sizeof c->st);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(100, "hipStreamCreate failed"); }
+    *out = c;
+    return 0;
+}
+
+int cora_hip_collapse_set_reference(cora_hip_collapse *c, const cora_hip_fasta *fa)
+{
+    if (!c || !fa) return fail(50, "null argument");
+    cora_hip_fasta_info fi;
+    RCQ(cora_hip_fasta_get_info(fa, &fi));
+    if (!c->prm.chr_short && fi.contigs > 250) return fail(19, "%llu contigs need the 2-byte layout (collapse_L; CL:62-77)", (unsigned long long)fi.contigs);
+    if (fi.contigs > 65530) return fail(19, "too many contigs (%llu, CL:330)", (unsigned long long)fi.contigs);
+    if (c->ref_job) { cora_hip_job_destroy(c->ref_job); c->ref_job = nullptr; }
+    cora_hip_params jp;
+    memset(&jp, 0, sizeof jp);
+    jp.K = 33; jp.d = 1; jp.chr_short = 1; jp.line_width = 1; jp.n_groups = 1; jp.n_threads = 1;      // only the packing stage of the job is used
+    memset(jp.sig2, 1, sizeof jp.sig2); memset(jp.sig4, 1, sizeof jp.sig4);
+    RCQ(cora_hip_job_create(&jp, &c->ref_job));
+    const int rc = cora_hip_job_set_reference_fasta(c->ref_job, fa);
+    if (rc) { cora_hip_job_destroy(c->ref_job); c->ref_job = nullptr; return rc; }
+    return 0;
+}
+
+int cora_hip_collapse_add_reads(cora_hip_collapse *c, const uint8_t *fastq, size_t bytes)
+{
+    if (!c || (!fastq && bytes)) return fail(5, "null argument");
+    cora_hip_collapse::File f;
+    f.off = (c->h_rd.size() + 15) & ~(size_t)15;
+    f.bytes = bytes;
+    c->h_rd.resize(f.off + bytes);
+    if (bytes) memcpy(c->h_rd.data() + f.off, fastq, bytes);
+    c->files.push_back(f);
+    return 0;
+}
+
+int cora_hip_collapse_run(cora_hip_collapse *c)
+{
+    if (!c) return fail(10, "null argument");
+    PoolScope no_pool(nullptr);
+    return run_impl(c);
+}
+
+int cora_hip_collapse_outputs(const cora_hip_collapse *c, const uint8_t **reads, size_t *reads_bytes, const uint8_t **perfect,
+                              size_t *perfect_bytes, const uint8_t **lrn, size_t *lrn_bytes)
+{
+    if (!c) return fail(10, "null argument");
+    if (reads) *reads = c->out_r.p; if (reads_bytes) *reads_bytes = c->n_r;
+    if (perfect) *perfect = c->out_p.p; if (perfect_bytes) *perfect_bytes = c->n_p;
+    if (lrn) *lrn = c->out_l.p; if (lrn_bytes) *lrn_bytes = c->n_l;
+    return 0;
+}
+
+int cora_hip_collapse_get_stats(const cora_hip_collapse *c, cora_hip_collapse_stats *out)
+{
+    if (!c || !out) return fail(10, "null argument");
+    *out = c->st;
+    return 0;
+}
+
+void cora_hip_collapse_destroy(cora_hip_collapse *c) { delete c; }
+
+}  // extern "C"

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict_
             const u64 off0 = p.ctg_off[c];
             u64 line = local0 / p.line_width;
             u32 col = (u32)(local0 - line * p.line_width);
-            u32 errs = 0;
+            u32 errs = 0, others = 0;
             badw = 0;
 #pragma unroll 4
             for (int i = 0; i < 32; i++) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict_
                     if (ch > 'Z') ch -= 32;
                     isbad = 0;
                     if (ch == 'A') code = 0; else if (ch == 'C') code = 1; else if (ch == 'G') code = 2; else if (ch == 'T') code = 3;
-                    else isbad = 1;
+                    else { isbad = 1; others += (ch != 'N'); }
                     if (col + 1 == p.line_width || local + 1 == len) {      // a line must end here
                         const u64 nl = at + 1;
                         if (nl < p.image_bytes && raw[nl] != '\n') errs++;
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict_
                 badw |= isbad << (31 - i);
             }
             if (errs) atomicAdd(&ctr->format_errors, (unsigned long long)errs);
+            if (others) atomicAdd(&ctr->other_letters, (unsigned long long)others);
         }
     }
     pk[w] = packed;

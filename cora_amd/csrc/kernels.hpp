@@ -55,6 +55,7 @@ struct DevCounters {
     unsigned long long n_mixed, fallback, first_singleton_key, n_pairs, n_candidates, n_dirty, format_errors;
     unsigned long long empty_contigs, emitted_nodes, emitted_exact, big_nodes, n_long;
     struct Huge { u32 n; u32 id[31]; } huge_entries, huge_write;   // classes too long for one workgroup (kernels.hip: HUGE_MIN)
+    unsigned long long other_letters;   // reference bytes that are neither A C G T nor N (after upper-casing): IUPAC codes and the like
 };
 
 

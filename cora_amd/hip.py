@@ -28,6 +28,8 @@ EXPORTS = [
     "cora_hip_tables_export", "cora_hip_tables_lookup_equiv", "cora_hip_tables_destroy",
     "cora_hip_fasta_scan", "cora_hip_fasta_get_info", "cora_hip_fasta_fai_text", "cora_hip_fasta_contig",
     "cora_hip_fasta_destroy", "cora_hip_job_set_reference_fasta",
+    "cora_hip_collapse_table_geometry", "cora_hip_collapse_create", "cora_hip_collapse_set_reference", "cora_hip_collapse_add_reads",
+    "cora_hip_collapse_run", "cora_hip_collapse_outputs", "cora_hip_collapse_get_stats", "cora_hip_collapse_destroy",
 ]
 
 
@@ -65,6 +67,22 @@ class TablesInfo(C.Structure):
 class FastaInfo(C.Structure):
     _fields_ = [("image_bytes", C.c_uint64), ("lines", C.c_uint64), ("contigs", C.c_uint64), ("bases", C.c_uint64),
                 ("conforming", C.c_int32), ("line_width", C.c_int32), ("ms_scan", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class CollapseParams(C.Structure):
+    _fields_ = [("digit_len", C.c_int32), ("read_len", C.c_int32), ("splits", C.c_int32), ("paired", C.c_int32),
+                ("mapper", C.c_int32), ("chr_short", C.c_int32), ("lrn_offset", C.c_uint64)]
+
+
+class CollapseStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "reads", "read_mers", "ref_windows", "distinct", "printed", "lrn_names", "hash_collisions", "reads_bytes",
+        "perfect_bytes", "lrn_bytes")] + [(n, C.c_float) for n in (
+        "ms_parse", "ms_keys", "ms_group", "ms_order", "ms_text", "ms_device", "ms_total", "ms_sort_scatter")] + [
+        ("n_sort_scatter", C.c_uint32), ("sort_scatter_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -133,6 +151,15 @@ def lib():
         L.cora_hip_fasta_destroy.argtypes = [C.c_void_p]
         L.cora_hip_fasta_destroy.restype = None
         L.cora_hip_job_set_reference_fasta.argtypes = [C.c_void_p, C.c_void_p]
+        L.cora_hip_collapse_table_geometry.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.cora_hip_collapse_create.argtypes = [C.POINTER(CollapseParams), C.POINTER(C.c_void_p)]
+        L.cora_hip_collapse_set_reference.argtypes = [C.c_void_p, C.c_void_p]
+        L.cora_hip_collapse_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cora_hip_collapse_run.argtypes = [C.c_void_p]
+        L.cora_hip_collapse_outputs.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.cora_hip_collapse_get_stats.argtypes = [C.c_void_p, C.POINTER(CollapseStats)]
+        L.cora_hip_collapse_destroy.argtypes = [C.c_void_p]
+        L.cora_hip_collapse_destroy.restype = None
         _lib = L
     return _lib
 

@@ -230,6 +230,57 @@ void cora_hip_fasta_destroy(cora_hip_fasta *f);
  * bytes; any other file is first gathered into a dense image on the GPU.  The job's params.line_width is ignored. */
 int cora_hip_job_set_reference_fasta(cora_hip_job *job, const cora_hip_fasta *f);
 
+/* ---- the read side: `collapse`, the read-mer collapsing stage of `cora search` ----
+ * CL = /root/reference/collapse.cpp.  Replaces its main() between "arguments parsed" and "files written" for the
+ * whole-input run mode (argv[13] = NONE, cora.cpp:1674-1692): reference read-mers (CL:647-711), read-mers of the reads,
+ * mates and splits (CL:861-2171), collapsing of identical canonical read-mers and the encoded ids (CL:276-289), and
+ * the text of the three output files in the iteration order of the reference's hash map (CL:2295-2405). */
+typedef struct cora_hip_collapse cora_hip_collapse;   /* opaque */
+
+typedef struct cora_hip_collapse_params {
+    int32_t digit_len;      /* argv[2]: characters per read-mer id (2..10) */
+    int32_t read_len;       /* argv[6]: length of an input read */
+    int32_t splits;         /* argv[11]: 1 FULL, 2 HALF, 3 THREEWAY (CL:568-588); read-mer length = read_len / splits */
+    int32_t paired;         /* argv[10]: 0 SINGLE, 1 PAIRED (files are then added as mate 1, mate 2 per sample) */
+    int32_t mapper;         /* argv[12]: 0 generic, 1 BWA, 2 BWA_MEM, 3 BOWTIE_2 (CL:590-611) */
+    int32_t chr_short;      /* 0: collapse (up to 250 contigs), 1: collapse_L (-DCHR_SHORT, CL:62-77) */
+    uint64_t lrn_offset;    /* argv[16]: long read names are numbered from this value + 1 (CL:541) */
+} cora_hip_collapse_params;
+
+typedef struct cora_hip_collapse_stats {
+    uint64_t reads;            /* sequence lines read (mates count separately) */
+    uint64_t read_mers;        /* reads x splits */
+    uint64_t ref_windows;      /* N-free reference windows of read-mer length */
+    uint64_t distinct;         /* distinct canonical read-mers (elements of the reference's hash map) */
+    uint64_t printed;          /* those that hold at least one read-mer of the input (CL:2311-2314) */
+    uint64_t lrn_names;        /* names moved to the long-read-name list (CL:2321-2328) */
+    uint64_t hash_collisions;  /* neighbours with one hash and different read-mers, re-ordered by the repair kernel */
+    uint64_t reads_bytes, perfect_bytes, lrn_bytes;
+    float ms_parse, ms_keys, ms_group, ms_order, ms_text, ms_device, ms_total;   /* HIP events; ms_total = wall of the run call */
+    float ms_sort_scatter;     /* time inside the radix scatter launches of this run */
+    uint32_t n_sort_scatter;
+    uint64_t sort_scatter_bytes;
+} cora_hip_collapse_stats;
+
+/* Bucket count of the reference's std::tr1::unordered_map after max_load_factor(1 / 1.13) and rehash(200000000)
+ * (CL:640-643) and the number of the element whose insertion makes it re-bucket itself, both asked of libstdc++'s own
+ * rehash policy at run time.  The output order follows from the first; runs that would reach the second are refused
+ * (status 77): the order after a re-bucketing is not reproduced. */
+int cora_hip_collapse_table_geometry(uint64_t *buckets, uint64_t *first_rehash_at);
+int cora_hip_collapse_create(const cora_hip_collapse_params *params, cora_hip_collapse **out);
+/* The reference (argv[4]; leave out for NOREF): a scanned FASTA.  The .fai and the line length (argv[5]) are not needed. */
+int cora_hip_collapse_set_reference(cora_hip_collapse *c, const cora_hip_fasta *reference);
+/* One FASTQ file image (host memory, copied), in the order of the list file (argv[1]): per sample the reads file, then,
+ * if paired, the mates file.  Records are four lines; the sequence line must hold at least read_len bytes of A C G T N
+ * (status 78 otherwise: the reference would cut its keys at the first other byte). */
+int cora_hip_collapse_add_reads(cora_hip_collapse *c, const uint8_t *fastq, size_t bytes);
+int cora_hip_collapse_run(cora_hip_collapse *c);
+/* The three files' bytes (argv[3], argv[7], argv[9]); valid until the next run or destroy. */
+int cora_hip_collapse_outputs(const cora_hip_collapse *c, const uint8_t **reads, size_t *reads_bytes, const uint8_t **perfect,
+                              size_t *perfect_bytes, const uint8_t **lrn, size_t *lrn_bytes);
+int cora_hip_collapse_get_stats(const cora_hip_collapse *c, cora_hip_collapse_stats *out);
+void cora_hip_collapse_destroy(cora_hip_collapse *c);
+
 /* ---- stage-level entry points (used by the parity tests and the benchmark) ---- */
 
 /* Stable LSD radix sort of n records on device memory, keyed on bits
