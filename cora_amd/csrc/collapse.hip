@@ -24,10 +24,12 @@ constexpr int CT = 256;
 constexpr u64 FNV_BASIS = 14695981039346656037ull, FNV_PRIME = 1099511628211ull;
 constexpr u32 ACGT_PACKED = 0x54474341u;       // 'A' 'C' 'G' 'T' by 2-bit code
 
-struct Src {               // where read-mers live
-    const u64 *pk;         // 2-bit packed reference (kernels.hip: k_pack)
-    const u8 *rd;          // FASTQ images
-    const u64 *seq_at;     // [reads] byte offset of each read's sequence line
+struct Src {               // where read-mers live: both sides 2-bit packed, 32 bases per u64, base i at bits 62 - 2 (i % 32)
+    const u64 *pk;         // the reference (kernels.hip: k_pack); windows that hold anything but A C G T never become records
+    u64 pk_words;
+    const u64 *rpk;        // the reads, sequence after sequence (k_reads_pack): read-mer idx starts at base idx * R
+    const u32 *rbad;       // one bit per read base, MSB first: the base is an N (its code in rpk is 0)
+    u64 rpk_words;
     u64 G;                 // ids below G are reference positions; id - G = running read-mer index
     u32 R, splits;
 };
@@ -35,60 +37,6 @@ struct Src {               // where read-mers live
 struct CollapseCounters {
     unsigned long long bad_read_bytes, n_mixed, n_owners, n_lrn, name_overflow;
 };
-
-__device__ __forceinline__ u32 comp_char(u32 c)
-{
-    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == 'N' ? 'N' : 0u;
-}
-
-struct Item { u64 base; bool is_ref; };
-
-__device__ __forceinline__ Item locate(const Src &s, u32 id)
-{
-    Item it;
-    it.is_ref = id < s.G;
-    if (it.is_ref) it.base = id;
-    else { const u64 idx = (u64)id - s.G; it.base = s.seq_at[idx / s.splits] + (idx % s.splits) * s.R; }
-    return it;
-}
-
-__device__ __forceinline__ u32 fwd_char(const Src &s, const Item &it, u32 i)
-{
-    if (it.is_ref) {
-        const u64 g = it.base + i;
-        const u32 code = (u32)(s.pk[g >> 5] >> (62 - 2 * (g & 31))) & 3u;
-        return (ACGT_PACKED >> (8 * code)) & 0xFFu;
-    }
-    return s.rd[it.base + i];
-}
-
-// CL:97-122: 1 iff the reverse complement is the lexicographically smaller one
-__device__ __forceinline__ u32 strand_of(const Src &s, const Item &it)
-{
-    for (u32 i = 0; i < s.R; i++) {
-        const u32 a = fwd_char(s, it, i), b = comp_char(fwd_char(s, it, s.R - 1 - i));
-        if (a < b) return 0;
-        if (a > b) return 1;
-    }
-    return 0;
-}
-
-__device__ __forceinline__ u32 canon_char(const Src &s, const Item &it, u32 sw, u32 i)
-{
-    return sw ? comp_char(fwd_char(s, it, s.R - 1 - i)) : fwd_char(s, it, i);
-}
-
-// <0, 0, >0: canonical read-mer of a against that of b
-__device__ int seq_cmp(const Src &s, u32 ida, u32 idb)
-{
-    const Item a = locate(s, ida), b = locate(s, idb);
-    const u32 sa = strand_of(s, a), sb = strand_of(s, b);
-    for (u32 i = 0; i < s.R; i++) {
-        const u32 x = canon_char(s, a, sa, i), y = canon_char(s, b, sb, i);
-        if (x != y) return x < y ? -1 : 1;
-    }
-    return 0;
-}
 
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *lds, u32 *total)
 {
@@ -107,6 +55,197 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *lds, u32 *total)
     if (total) *total = tot;
     __syncthreads();
     return base + x - v;
+}
+
+// ------------------------------------------------------------------ a read-mer as words
+// The canonical form (CL:97-122: the reverse complement when it is the lexicographically smaller string, ASCII order
+// A < C < G < N < T) of a read-mer of up to 32 W bases: codes left-aligned in c[], N positions in m[] (code 0 there).
+template <int W>
+struct Mer { u64 c[W]; u32 m[W]; u32 sw; };
+
+__device__ __forceinline__ u64 rev2(u64 x)     // order of the 32 two-bit groups reversed
+{
+    x = __brevll(x);
+    return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+
+__device__ __forceinline__ u64 spread2(u32 m)  // bit i -> bits 2i and 2i + 1
+{
+    u64 x = m;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x | (x << 1);
+}
+
+__device__ __forceinline__ u64 ldw(const u64 *p, long long i, u64 n) { return (i >= 0 && (u64)i < n) ? p[i] : 0ull; }
+__device__ __forceinline__ u32 ldm(const u32 *p, long long i, u64 n) { return (i >= 0 && (u64)i < n) ? p[i] : 0u; }
+
+// The forward words come from a funnel shift that puts the first base at the top of word 0; the reverse complement from
+// a second one that puts the LAST base at the bottom of word W - 1, so that reversing it is a fixed permutation of words.
+template <int W>
+__device__ __forceinline__ void canon(const Src &s, u32 id, Mer<W> &o)
+{
+    const bool is_ref = id < s.G;
+    const u64 base = is_ref ? (u64)id : ((u64)id - s.G) * s.R;
+    const u64 *p = is_ref ? s.pk : s.rpk;
+    const u64 nw = is_ref ? s.pk_words : s.rpk_words;
+    const u32 R = s.R;
+    const long long lw0 = (long long)(base >> 5);
+    const u32 lo = (u32)(base & 31);
+    const long long s0 = (long long)(base + R) - 32 * W;
+    const long long rw0 = s0 >> 5;
+    const u32 ro = (u32)(s0 & 31);
+    u64 fw[W], rc[W];
+    {
+        u64 prev = ldw(p, lw0, nw);
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const u64 next = (32u * (k + 1) < lo + R) ? ldw(p, lw0 + k + 1, nw) : 0ull;
+            fw[k] = lo ? (prev << (2 * lo)) | (next >> (64 - 2 * lo)) : prev;
+            prev = next;
+        }
+    }
+    {
+        u64 prev = ((rw0 + 1) * 32 > (long long)base) ? ldw(p, rw0, nw) : 0ull;
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const u64 next = ((rw0 + k + 2) * 32 > (long long)base) ? ldw(p, rw0 + k + 1, nw) : 0ull;
+            const u64 x = ro ? (prev << (2 * ro)) | (next >> (64 - 2 * ro)) : prev;
+            rc[W - 1 - k] = ~rev2(x);
+            prev = next;
+        }
+    }
+    u32 ml[W], mr[W];
+    u32 any_n = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const u32 nb = R > 32u * k ? min(32u, R - 32u * k) : 0u;
+        const u64 mask = nb == 32 ? ~0ull : nb ? ~0ull << (64 - 2 * nb) : 0ull;
+        fw[k] &= mask; rc[k] &= mask;
+        ml[k] = mr[k] = 0;
+    }
+    if (!is_ref) {
+        const u32 *b = s.rbad;
+        u32 prev = ldm(b, lw0, nw);
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const u32 next = (32u * (k + 1) < lo + R) ? ldm(b, lw0 + k + 1, nw) : 0u;
+            const u32 nb = R > 32u * k ? min(32u, R - 32u * k) : 0u;
+            const u32 mask = nb == 32 ? ~0u : nb ? ~0u << (32 - nb) : 0u;
+            ml[k] = (lo ? (prev << lo) | (next >> (32 - lo)) : prev) & mask;
+            any_n |= ml[k];
+            prev = next;
+        }
+        if (any_n) {
+            prev = ((rw0 + 1) * 32 > (long long)base) ? ldm(b, rw0, nw) : 0u;
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const u32 next = ((rw0 + k + 2) * 32 > (long long)base) ? ldm(b, rw0 + k + 1, nw) : 0u;
+                mr[W - 1 - k] = __brev(ro ? (prev << ro) | (next >> (32 - ro)) : prev);
+                prev = next;
+            }
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const u32 nb = R > 32u * k ? min(32u, R - 32u * k) : 0u;
+                mr[k] &= nb == 32 ? ~0u : nb ? ~0u << (32 - nb) : 0u;
+                rc[k] &= ~spread2(mr[k]);
+            }
+        }
+    }
+    u32 sw = 0;
+    bool decided = false;
+    if (!any_n) {
+#pragma unroll
+        for (int k = 0; k < W; k++)
+            if (!decided && fw[k] != rc[k]) { decided = true; sw = fw[k] > rc[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const u64 D = (fw[k] ^ rc[k]) | spread2(ml[k] ^ mr[k]);
+            if (!decided && D) {
+                decided = true;
+                const u32 q = (u32)__clzll((long long)D) >> 1;
+                const u32 a = (u32)(fw[k] >> (62 - 2 * q)) & 3u, bb = (u32)(rc[k] >> (62 - 2 * q)) & 3u;
+                const u32 ra = ((ml[k] >> (31 - q)) & 1u) ? 3u : (a == 3 ? 4u : a);
+                const u32 rb = ((mr[k] >> (31 - q)) & 1u) ? 3u : (bb == 3 ? 4u : bb);
+                sw = ra > rb;
+            }
+        }
+    }
+    o.sw = sw;
+#pragma unroll
+    for (int k = 0; k < W; k++) { o.c[k] = sw ? rc[k] : fw[k]; o.m[k] = sw ? mr[k] : ml[k]; }
+}
+
+// tr1::hash<string> of the canonical read-mer: FNV-1a 64 over its R characters (sequential by definition: ALU work)
+template <int W>
+__device__ __forceinline__ u64 fnv_of(const Mer<W> &m, u32 R)
+{
+    u64 h = FNV_BASIS;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const u32 n = R > 32u * k ? min(32u, R - 32u * k) : 0u;
+        u64 c = m.c[k];
+        u32 mm = m.m[k];
+        for (u32 j = 0; j < n; j++) {
+            u32 ch = (ACGT_PACKED >> (8 * (u32)(c >> 62))) & 0xFFu;
+            if (mm & 0x80000000u) ch = 'N';
+            h = (h ^ ch) * FNV_PRIME;
+            c <<= 2; mm <<= 1;
+        }
+    }
+    return h;
+}
+
+template <int W, class P>
+__device__ __forceinline__ void put_mer(P dst, const Mer<W> &m, u32 R)
+{
+    u32 i = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const u32 n = R > 32u * k ? min(32u, R - 32u * k) : 0u;
+        u64 c = m.c[k];
+        u32 mm = m.m[k];
+        for (u32 j = 0; j < n; j++) {
+            u32 ch = (ACGT_PACKED >> (8 * (u32)(c >> 62))) & 0xFFu;
+            if (mm & 0x80000000u) ch = 'N';
+            dst[i++] = (u8)ch;
+            c <<= 2; mm <<= 1;
+        }
+    }
+}
+
+// <0, 0, >0: a total order on canonical read-mers (any one will do: it only has to bring equal ones together)
+template <int W>
+__device__ __forceinline__ int mer_cmp(const Mer<W> &a, const Mer<W> &b)
+{
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        if (r == 0 && a.c[k] != b.c[k]) r = a.c[k] < b.c[k] ? -1 : 1;
+        if (r == 0 && a.m[k] != b.m[k]) r = a.m[k] < b.m[k] ? -1 : 1;
+    }
+    return r;
+}
+
+template <int W>
+__device__ __forceinline__ int seq_cmp(const Src &s, u32 ida, u32 idb)
+{
+    Mer<W> a, b;
+    canon<W>(s, ida, a);
+    canon<W>(s, idb, b);
+    return mer_cmp<W>(a, b);
+}
+
+template <int W>
+__device__ __forceinline__ u32 strand_of(const Src &s, u32 id)
+{
+    Mer<W> a;
+    canon<W>(s, id, a);
+    return a.sw;
 }
 
 // ------------------------------------------------------------------ FASTQ: sequence line of every record
@@ -151,6 +290,33 @@ __global__ __launch_bounds__(CT) void k_fq_emit(const u8 *__restrict__ img, u64 
     }
 }
 
+// The first RL = splits * R bases of every sequence line, packed one read behind the other: one thread per 32 bases.
+// A byte outside A C G T N (a line end included: the line is shorter than RL) is counted; the run is refused then.
+__global__ __launch_bounds__(CT) void k_reads_pack(const u8 *__restrict__ rd, const u64 *__restrict__ seq_at, u64 n_rd, u32 RL,
+                                                   u64 *__restrict__ rpk, u32 *__restrict__ rbad, u64 n_words, CollapseCounters *ctr)
+{
+    const u64 w = (u64)blockIdx.x * CT + threadIdx.x;
+    if (w >= n_words) return;
+    const u64 total = n_rd * RL, b0 = w * 32;
+    u64 code = 0;
+    u32 nm = 0, bad = 0;
+    if (b0 < total) {
+        u64 r = b0 / RL;
+        u32 o = (u32)(b0 - r * RL);
+        const u8 *p = rd + seq_at[r];
+        const u32 n = (u32)min((u64)32, total - b0);
+        for (u32 j = 0; j < n; j++) {
+            const u32 c = p[o];
+            const u32 v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+            if (v == 4) { nm |= 0x80000000u >> j; bad += c != 'N'; }
+            else code |= (u64)v << (62 - 2 * j);
+            if (++o == RL) { o = 0; r++; if (r < n_rd) p = rd + seq_at[r]; }
+        }
+    }
+    rpk[w] = code; rbad[w] = nm;
+    if (bad) atomicAdd(&ctr->bad_read_bytes, (unsigned long long)bad);
+}
+
 // ------------------------------------------------------------------ reference windows
 __global__ __launch_bounds__(CT) void k_win_count(u64 G, u32 R, const u32 *__restrict__ bad, u32 *__restrict__ blk, u32 *__restrict__ wvalid)
 {
@@ -173,6 +339,7 @@ __global__ __launch_bounds__(CT) void k_win_count(u64 G, u32 R, const u32 *__res
     if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+template <int W>
 __global__ __launch_bounds__(CT) void k_win_emit(Src s, const u32 *__restrict__ wvalid, const u64 *__restrict__ blk_off,
                                                  u64 *__restrict__ key, u32 *__restrict__ id)
 {
@@ -181,53 +348,26 @@ __global__ __launch_bounds__(CT) void k_win_emit(Src s, const u32 *__restrict__ 
     const bool ok = g < s.G && ((wvalid[g >> 5] >> (31 - (u32)(g & 31))) & 1u);
     const u32 r = block_excl_scan(ok ? 1u : 0u, lds, nullptr);
     if (!ok) return;
-    Item it; it.base = g; it.is_ref = true;
-    const u32 sw = strand_of(s, it);
-    u64 h = FNV_BASIS;
-    if (!sw) {
-        u64 q = g, w = s.pk[q >> 5];
-        for (u32 i = 0; i < s.R; i++, q++) {
-            if ((q & 31) == 0) w = s.pk[q >> 5];
-            const u32 code = (u32)(w >> (62 - 2 * (q & 31))) & 3u;
-            h = (h ^ ((ACGT_PACKED >> (8 * code)) & 0xFFu)) * FNV_PRIME;
-        }
-    } else {
-        u64 q = g + s.R - 1, w = s.pk[q >> 5];
-        for (u32 i = 0; i < s.R; i++, q--) {
-            if ((q & 31) == 31) w = s.pk[q >> 5];
-            const u32 code = 3u - ((u32)(w >> (62 - 2 * (q & 31))) & 3u);
-            h = (h ^ ((ACGT_PACKED >> (8 * code)) & 0xFFu)) * FNV_PRIME;
-        }
-    }
+    Mer<W> m;
+    canon<W>(s, (u32)g, m);
     const u64 at = blk_off[blockIdx.x] + r;
-    key[at] = h; id[at] = (u32)g;
+    key[at] = fnv_of<W>(m, s.R); id[at] = (u32)g;
 }
 
 // ------------------------------------------------------------------ read-mers of the input
-__global__ __launch_bounds__(CT) void k_read_keys(Src s, u64 n_items, u64 out_base, u64 *__restrict__ key, u32 *__restrict__ id,
-                                                  CollapseCounters *ctr)
+template <int W>
+__global__ __launch_bounds__(CT) void k_read_keys(Src s, u64 n_items, u64 out_base, u64 *__restrict__ key, u32 *__restrict__ id)
 {
     const u64 idx = (u64)blockIdx.x * CT + threadIdx.x;
     if (idx >= n_items) return;
-    Item it;
-    it.is_ref = false;
-    it.base = s.seq_at[idx / s.splits] + (idx % s.splits) * s.R;
-    const u8 *p = s.rd + it.base;
-    u32 sw = 0, bad = 0;
-    for (u32 i = 0; i < s.R; i++) {
-        const u32 a = p[i], b = comp_char(p[s.R - 1 - i]);
-        if (a < b) break;
-        if (a > b) { sw = 1; break; }
-    }
-    u64 h = FNV_BASIS;
-    if (!sw) for (u32 i = 0; i < s.R; i++) { const u32 c = p[i]; bad += comp_char(c) == 0; h = (h ^ c) * FNV_PRIME; }
-    else for (u32 i = 0; i < s.R; i++) { const u32 c = comp_char(p[s.R - 1 - i]); bad += c == 0; h = (h ^ c) * FNV_PRIME; }
-    if (bad) atomicAdd(&ctr->bad_read_bytes, (unsigned long long)bad);
-    key[out_base + idx] = h; id[out_base + idx] = (u32)(s.G + idx);
+    Mer<W> m;
+    canon<W>(s, (u32)(s.G + idx), m);
+    key[out_base + idx] = fnv_of<W>(m, s.R); id[out_base + idx] = (u32)(s.G + idx);
 }
 
 // ------------------------------------------------------------------ groups of equal read-mers
 // head: 1 = first record of a group; 2 = same hash as the record before but another read-mer (repaired below)
+template <int W>
 __global__ __launch_bounds__(CT) void k_heads(Src s, const u64 *__restrict__ key, const u32 *__restrict__ id, u64 n, u64 mask,
                                               u32 *__restrict__ head, CollapseCounters *ctr)
 {
@@ -235,7 +375,7 @@ __global__ __launch_bounds__(CT) void k_heads(Src s, const u64 *__restrict__ key
     if (i >= n) return;
     u32 h = 1;
     if (i > 0 && ((key[i] ^ key[i - 1]) & mask) == 0) {
-        h = seq_cmp(s, id[i], id[i - 1]) == 0 ? 0u : 2u;
+        h = seq_cmp<W>(s, id[i], id[i - 1]) == 0 ? 0u : 2u;
         if (h == 2) atomicAdd(&ctr->n_mixed, 1ull);
     }
     head[i] = h;
@@ -253,6 +393,7 @@ __global__ __launch_bounds__(CT) void k_mixed_owners(const u64 *__restrict__ key
 }
 
 // one thread per run: stable insertion sort of the run's ids by read-mer, then the group heads inside the run
+template <int W>
 __global__ __launch_bounds__(64) void k_mixed_fix(Src s, u64 *__restrict__ key, u32 *__restrict__ id, u64 n, u64 mask,
                                                   u32 *__restrict__ head, const u32 *__restrict__ owners, u64 n_owners)
 {
@@ -264,11 +405,18 @@ __global__ __launch_bounds__(64) void k_mixed_fix(Src s, u64 *__restrict__ key, 
     for (u64 a = st + 1; a < en; a++) {
         const u32 x = id[a];
         const u64 kx = key[a];                  // the full hashes differ inside a run when the sort looked at fewer bits
+        Mer<W> mx;
+        canon<W>(s, x, mx);
         u64 b = a;
-        while (b > st && seq_cmp(s, x, id[b - 1]) < 0) { id[b] = id[b - 1]; key[b] = key[b - 1]; b--; }
+        while (b > st) {
+            Mer<W> mo;
+            canon<W>(s, id[b - 1], mo);
+            if (mer_cmp<W>(mx, mo) >= 0) break;
+            id[b] = id[b - 1]; key[b] = key[b - 1]; b--;
+        }
         id[b] = x; key[b] = kx;
     }
-    for (u64 q = st + 1; q < en; q++) head[q] = seq_cmp(s, id[q], id[q - 1]) == 0 ? 0u : 1u;
+    for (u64 q = st + 1; q < en; q++) head[q] = seq_cmp<W>(s, id[q], id[q - 1]) == 0 ? 0u : 1u;
 }
 
 __global__ __launch_bounds__(CT) void k_group_starts(const u32 *__restrict__ head, const u64 *__restrict__ gex, u64 n, u32 *__restrict__ gstart,
@@ -316,7 +464,8 @@ struct OutParams {
 };
 
 __device__ __forceinline__ u32 dec_digits(u64 v) { u32 n = 1; while (v >= 10) { v /= 10; n++; } return n; }
-__device__ __forceinline__ u32 put_dec(u8 *dst, u64 v)
+template <class P>
+__device__ __forceinline__ u32 put_dec(P dst, u64 v)
 {
     const u32 n = dec_digits(v);
     for (u32 k = n; k-- > 0;) { dst[k] = (u8)('0' + v % 10); v /= 10; }
@@ -324,10 +473,11 @@ __device__ __forceinline__ u32 put_dec(u8 *dst, u64 v)
 }
 
 // id digits of the read-mer at sorted position q of a group whose first record is `first` (CL:948-972, 276-289, 491-506)
+template <int W>
 __device__ __forceinline__ u64 id_value(const Src &s, const u32 *__restrict__ id, u32 q, bool in_ref, u32 ref_dir)
 {
     const u32 x = id[q];
-    const u32 sw = strand_of(s, locate(s, x));
+    const u32 sw = strand_of<W>(s, x);
     return 2 * ((u64)x - s.G) + (in_ref ? (sw != ref_dir) : sw);
 }
 
@@ -337,6 +487,7 @@ __device__ __forceinline__ u32 lrn_len(u64 number, u32 D)
     return n + 2 + ((n + 2) % D == 0 ? 1u : 0u);                        // CL:312-326
 }
 
+template <int W>
 __global__ __launch_bounds__(CT) void k_out_flags(Src s, OutParams op, const u32 *__restrict__ id, const u32 *__restrict__ gstart,
                                                   const u32 *__restrict__ oval, u64 m, u32 *__restrict__ lrn_flag, CollapseCounters *ctr)
 {
@@ -350,7 +501,7 @@ __global__ __launch_bounds__(CT) void k_out_flags(Src s, OutParams op, const u32
         if (name_len > 0xF0000000ull) atomicAdd(&ctr->name_overflow, 1ull);
         if (op.mapper == 0 || op.mapper == 3) lrn = name_len > 194;                                    // CL:2321, 2381
         else {
-            const u64 v = id_value(s, id, en - 1, false, 0);
+            const u64 v = id_value<W>(s, id, en - 1, false, 0);
             const u32 c2 = (u32)(v % 94) + 33, c1 = (u32)((v / 94) % 94) + 33;                         // D >= 2
             lrn = name_len > 5000000 || (c1 == '/' && (op.mapper == 1 ? (c2 == '1' || c2 == '2') : (c2 >= '0' && c2 <= '9')));   // CL:2339-2342, 2360-2363
         }
@@ -389,62 +540,47 @@ __global__ __launch_bounds__(CT) void k_out_sizes(Src s, OutParams op, const u32
     sz_r[j] = r; sz_p[j] = p; sz_l[j] = l;
 }
 
-__device__ __forceinline__ void put_name(const Src &s, u32 D, const u32 *__restrict__ id, u32 fr, u32 en, bool in_ref, u32 ref_dir, u8 *dst)
+template <int W, class P>
+__device__ __forceinline__ void put_name(const Src &s, u32 D, const u32 *__restrict__ id, u32 fr, u32 en, bool in_ref, u32 ref_dir, P dst)
 {
     for (u32 q = fr; q < en; q++, dst += D) {
-        u64 v = id_value(s, id, q, in_ref, ref_dir);
+        u64 v = id_value<W>(s, id, q, in_ref, ref_dir);
         for (u32 k = D; k-- > 0;) { dst[k] = (u8)(v % 94 + 33); v /= 94; }
     }
 }
 
-__global__ __launch_bounds__(CT) void k_out_write(Src s, OutParams op, const u32 *__restrict__ id, const u32 *__restrict__ gstart,
-                                                  const u32 *__restrict__ oval, u64 m, const u32 *__restrict__ lrn_flag,
-                                                  const u64 *__restrict__ lrn_rank, const u64 *__restrict__ off_r,
-                                                  const u64 *__restrict__ off_p, const u64 *__restrict__ off_l, u8 *__restrict__ out_r,
-                                                  u8 *__restrict__ out_p, u8 *__restrict__ out_l)
+struct Group { u32 first, fr, en, name_len; bool in_ref; };
+
+// one line of the perfect-match file (CL:2400-2401)
+template <int W, class P>
+__device__ __forceinline__ void write_perfect(const Src &s, const OutParams &op, const u32 *__restrict__ id, const Group &g, u32 head_sw, P w)
 {
-    const u64 j = (u64)blockIdx.x * CT + threadIdx.x;
-    if (j >= m) return;
-    const u32 g = oval[j], st = gstart[g], en = gstart[g + 1];
-    const u32 first = id[st];
-    const bool in_ref = first < s.G;
-    const u32 fr = first_read_of(id, st, en, s.G);
-    const u32 name_len = op.D * (en - fr);
-    const Item head = locate(s, first);
-    const u32 head_sw = strand_of(s, head);
-    if (in_ref) {
-        u8 *w = out_p + off_p[j];
-        put_name(s, op.D, id, fr, en, true, head_sw, w);
-        w += name_len;
-        u32 code, pos;
-        ref_place(op, first, code, pos);
-        *w++ = '\t'; w += put_dec(w, code);
-        *w++ = '\t'; w += put_dec(w, pos);
-        *w++ = '\t'; w += put_dec(w, s.R);
-        *w = '\n';
-        return;
-    }
-    u8 *w = out_r + off_r[j];
+    put_name<W>(s, op.D, id, g.fr, g.en, true, head_sw, w);
+    w += g.name_len;
+    u32 code, pos;
+    ref_place(op, g.first, code, pos);
+    *w++ = '\t'; w += put_dec(w, code);
+    *w++ = '\t'; w += put_dec(w, pos);
+    *w++ = '\t'; w += put_dec(w, s.R);
+    *w = '\n';
+}
+
+// one record of the collapsed-reads file (CL:2317-2396); `shown` = 0: the name itself, else the long-read-name number
+template <int W, class P>
+__device__ __forceinline__ void write_read(const Src &s, const OutParams &op, const u32 *__restrict__ id, const Group &g, const Mer<W> &head,
+                                           u64 lrn_number, P w)
+{
     *w++ = op.mapper == 3 ? '@' : '>';
-    if (lrn_flag[j]) {
-        u8 *l = out_l + off_l[j];
-        const u64 number = op.lrn_offset + lrn_rank[j] + 1;
-        const u32 n = dec_digits(number), extra = (n + 2) % op.D == 0;
-        for (int copy = 0; copy < 2; copy++) {
-            u8 *c = copy ? l : w;
-            *c++ = '#'; c += put_dec(c, number); *c++ = '#';
-            if (extra) *c++ = '#';
-            if (copy) l = c; else w = c;
-        }
-        *l++ = '\t';
-        put_name(s, op.D, id, fr, en, false, 0, l);
-        l[name_len] = '\n';
+    if (lrn_number) {
+        const u32 n = dec_digits(lrn_number), extra = (n + 2) % op.D == 0;
+        *w++ = '#'; w += put_dec(w, lrn_number); *w++ = '#';
+        if (extra) *w++ = '#';
     } else {
-        put_name(s, op.D, id, fr, en, false, 0, w);
-        w += name_len;
+        put_name<W>(s, op.D, id, g.fr, g.en, false, 0, w);
+        w += g.name_len;
     }
     *w++ = '\n';
-    for (u32 i = 0; i < s.R; i++) w[i] = (u8)canon_char(s, head, head_sw, i);
+    put_mer<W>(w, head, s.R);
     w += s.R;
     *w++ = '\n';
     if (op.mapper == 3) {                                                                              // CL:2394-2395
@@ -454,7 +590,103 @@ __global__ __launch_bounds__(CT) void k_out_write(Src s, OutParams op, const u32
     }
 }
 
+// one line of the long-read-name file (CL:312-326)
+template <int W, class P>
+__device__ __forceinline__ void write_lrn(const Src &s, const OutParams &op, const u32 *__restrict__ id, const Group &g, u64 lrn_number, P l)
+{
+    const u32 n = dec_digits(lrn_number), extra = (n + 2) % op.D == 0;
+    *l++ = '#'; l += put_dec(l, lrn_number); *l++ = '#';
+    if (extra) *l++ = '#';
+    *l++ = '\t';
+    put_name<W>(s, op.D, id, g.fr, g.en, false, 0, l);
+    l[g.name_len] = '\n';
+}
+
+constexpr u32 STAGE_BYTES = 48 * 1024;
+
+// bytes [0, total) staged at lds[lead ...] -> out[base ...], 16 bytes per lane where whole chunks exist (lead = base % 16, so
+// LDS and global addresses are aligned alike)
+__device__ __forceinline__ void flush_stage(const u8 *lds, u8 *__restrict__ out, u64 base, u32 total)
+{
+    const u32 lead = (u32)(base & 15);
+    u8 *abase = out + (base - lead);
+    const u32 end = lead + total, chunks = (end + 15) / 16;
+    for (u32 c = threadIdx.x; c < chunks; c += CT) {
+        const u32 lo = c * 16, hi = lo + 16;
+        if (lo >= lead && hi <= end) *reinterpret_cast<uint4 *>(abase + lo) = *reinterpret_cast<const uint4 *>(lds + lo);
+        else for (u32 b = max(lo, lead); b < min(hi, end); b++) abase[b] = lds[b];
+    }
+}
+
+// A workgroup's records are consecutive in each of the three files, so it builds its piece of each file in LDS and
+// writes it out in whole 16-byte chunks; a piece that does not fit (long names: heavily repeated read-mers) is written
+// record by record straight to memory.
+template <int W>
+__global__ __launch_bounds__(CT) void k_out_write(Src s, OutParams op, const u32 *__restrict__ id, const u32 *__restrict__ gstart,
+                                                  const u32 *__restrict__ oval, u64 m, const u32 *__restrict__ lrn_flag,
+                                                  const u64 *__restrict__ lrn_rank, const u64 *__restrict__ off_r,
+                                                  const u64 *__restrict__ off_p, const u64 *__restrict__ off_l,
+                                                  const u32 *__restrict__ sz_r, const u32 *__restrict__ sz_p, const u32 *__restrict__ sz_l,
+                                                  u8 *__restrict__ out_r, u8 *__restrict__ out_p, u8 *__restrict__ out_l)
+{
+    __shared__ __align__(16) u8 stage[STAGE_BYTES + 16];
+    const u64 j0 = (u64)blockIdx.x * CT, j = j0 + threadIdx.x;
+    const u64 jl = min(j0 + CT, m) - 1;
+    const bool live = j < m;
+    Group g;
+    g.first = 0; g.fr = g.en = 0; g.name_len = 0; g.in_ref = false;
+    Mer<W> head;
+    u64 lrn_number = 0;
+    if (live) {
+        const u32 gi = oval[j], st = gstart[gi];
+        g.en = gstart[gi + 1];
+        g.first = id[st];
+        g.in_ref = g.first < s.G;
+        g.fr = first_read_of(id, st, g.en, s.G);
+        g.name_len = op.D * (g.en - g.fr);
+        canon<W>(s, g.first, head);
+        if (!g.in_ref && lrn_flag[j]) lrn_number = op.lrn_offset + lrn_rank[j] + 1;
+    }
+    {   // collapsed reads
+        const u64 base = off_r[j0], total = off_r[jl] + sz_r[jl] - base;
+        const bool mine = live && !g.in_ref;
+        if (total <= STAGE_BYTES) {
+            if (mine) write_read<W>(s, op, id, g, head, lrn_number, stage + (u32)(base & 15) + (u32)(off_r[j] - base));
+            __syncthreads();
+            flush_stage(stage, out_r, base, (u32)total);
+            __syncthreads();
+        } else if (mine) write_read<W>(s, op, id, g, head, lrn_number, out_r + off_r[j]);
+    }
+    {   // perfect matches
+        const u64 base = off_p[j0], total = off_p[jl] + sz_p[jl] - base;
+        const bool mine = live && g.in_ref;
+        if (total <= STAGE_BYTES) {
+            if (mine) write_perfect<W>(s, op, id, g, head.sw, stage + (u32)(base & 15) + (u32)(off_p[j] - base));
+            __syncthreads();
+            flush_stage(stage, out_p, base, (u32)total);
+            __syncthreads();
+        } else if (mine) write_perfect<W>(s, op, id, g, head.sw, out_p + off_p[j]);
+    }
+    {   // long read names
+        const u64 base = off_l[j0], total = off_l[jl] + sz_l[jl] - base;
+        const bool mine = live && lrn_number != 0;
+        if (total == 0) return;
+        if (total <= STAGE_BYTES) {
+            if (mine) write_lrn<W>(s, op, id, g, lrn_number, stage + (u32)(base & 15) + (u32)(off_l[j] - base));
+            __syncthreads();
+            flush_stage(stage, out_l, base, (u32)total);
+        } else if (mine) write_lrn<W>(s, op, id, g, lrn_number, out_l + off_l[j]);
+    }
+}
+
 u32 grid_of(u64 n, u32 per) { const u64 g = (n + per - 1) / per; return (u32)(g ? g : 1); }
+
+// kernels over read-mers exist for 4 words (up to 128 bases) and 10 words (up to 320; the reference stops below 300, CL:27)
+#define LAUNCH_W(kernel, grid, block, stream, ...)                                                              \
+    do {                                                                                                        \
+        if (R <= 128) hipLaunchKernelGGL(kernel<4>, grid, block, 0, stream, __VA_ARGS__);                        \
+        else hipLaunchKernelGGL(kernel<10>, grid, block, 0, stream, __VA_ARGS__);                                \
+    } while (0)
 
 }  // namespace
 
@@ -512,6 +744,7 @@ int run_impl(cora_hip_collapse *c)
     if (c->files.size() % stride) return fail(6, "paired input needs two files per sample");
     DBuf<u8> rd;
     RCQ(rd.alloc(c->h_rd.size() + 1024));
+    HIPQ(hipMemsetAsync(rd.p + c->h_rd.size(), 0, 1024, s));
     if (!c->h_rd.empty()) HIPQ(hipMemcpyAsync(rd.p, c->h_rd.data(), c->h_rd.size(), hipMemcpyHostToDevice, s));
     HIPQ(hipEventRecord(ev[0], s));
     std::vector<u64> file_records(c->files.size());
@@ -540,8 +773,10 @@ int run_impl(cora_hip_collapse *c)
     }
     const u64 n_rd = n_reads * stride;                      // sequence lines
     const u64 n_items = n_rd * splits;
-    DBuf<u64> seq_at;
-    RCQ(seq_at.alloc(n_rd + 1));
+    DBuf<u64> seq_at, rpk;
+    DBuf<u32> rbad;
+    const u64 rpk_words = (n_items * R + 31) / 32 + 12;
+    RCQ(seq_at.alloc(n_rd + 1)); RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words));
     {
         u64 first = 0;
         for (size_t f = 0; f < c->files.size(); f++) {
@@ -551,6 +786,7 @@ int run_impl(cora_hip_collapse *c)
                                seq_at.p + mate, first, stride, file_records[f]);
             if (!prm.paired || (f & 1)) first += file_records[f];
         }
+        hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, rd.p, seq_at.p, n_rd, R * splits, rpk.p, rbad.p, rpk_words, ctr.p);
     }
 
     // ---- the reference: packed by the table builder's kernel ----
@@ -585,12 +821,13 @@ int run_impl(cora_hip_collapse *c)
 
     // ---- records ----
     Src src;
-    src.pk = rj ? rj->pk.p : nullptr; src.rd = rd.p; src.seq_at = seq_at.p; src.G = G; src.R = R; src.splits = splits;
+    src.pk = rj ? rj->pk.p : nullptr; src.pk_words = rj ? rj->pk.n : 0; src.rpk = rpk.p; src.rbad = rbad.p; src.rpk_words = rpk_words;
+    src.G = G; src.R = R; src.splits = splits;
     DBuf<u64> key, tkey;
     DBuf<u32> id, tid;
     RCQ(key.alloc(N + 1)); RCQ(tkey.alloc(N + 1)); RCQ(id.alloc(N + 1)); RCQ(tid.alloc(N + 1));
-    if (rj && G) hipLaunchKernelGGL(k_win_emit, dim3(grid_of(G, CT)), dim3(CT), 0, s, src, wvalid.p, woff.p, key.p, id.p);
-    if (n_items) hipLaunchKernelGGL(k_read_keys, dim3(grid_of(n_items, CT)), dim3(CT), 0, s, src, n_items, NW, key.p, id.p, ctr.p);
+    if (rj && G) LAUNCH_W(k_win_emit, dim3(grid_of(G, CT)), dim3(CT), s, src, wvalid.p, woff.p, key.p, id.p);
+    if (n_items) LAUNCH_W(k_read_keys, dim3(grid_of(n_items, CT)), dim3(CT), s, src, n_items, NW, key.p, id.p);
     CollapseCounters hc;
     HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
@@ -612,7 +849,7 @@ int run_impl(cora_hip_collapse *c)
     u32 *sid = ka.c;
     DBuf<u32> head;
     RCQ(head.alloc(N + 1));
-    if (N) hipLaunchKernelGGL(k_heads, dim3(grid_of(N, CT)), dim3(CT), 0, s, src, skey, sid, N, mask, head.p, ctr.p);
+    if (N) LAUNCH_W(k_heads, dim3(grid_of(N, CT)), dim3(CT), s, src, skey, sid, N, mask, head.p, ctr.p);
     HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
     st.hash_collisions = hc.n_mixed;
@@ -622,7 +859,7 @@ int run_impl(cora_hip_collapse *c)
         hipLaunchKernelGGL(k_mixed_owners, dim3(grid_of(N, CT)), dim3(CT), 0, s, skey, head.p, N, mask, owners.p, ctr.p);
         HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
-        hipLaunchKernelGGL(k_mixed_fix, dim3(grid_of(hc.n_owners, 64)), dim3(64), 0, s, src, skey, sid, N, mask, head.p, owners.p, (u64)hc.n_owners);
+        LAUNCH_W(k_mixed_fix, dim3(grid_of(hc.n_owners, 64)), dim3(64), s, src, skey, sid, N, mask, head.p, owners.p, (u64)hc.n_owners);
         HIPQ(hipStreamSynchronize(s));
     }
     u64 n_groups = 0;
@@ -683,7 +920,7 @@ int run_impl(cora_hip_collapse *c)
     c->n_r = c->n_p = c->n_l = 0;
     if (M) {
         const u32 gb = grid_of(M, CT);
-        hipLaunchKernelGGL(k_out_flags, dim3(gb), dim3(CT), 0, s, src, op, sid, gstart.p, ord, M, lrn_flag.p, ctr.p);
+        LAUNCH_W(k_out_flags, dim3(gb), dim3(CT), s, src, op, sid, gstart.p, ord, M, lrn_flag.p, ctr.p);
         RCQ(scan_u32(s, lrn_flag.p, lrn_rank.p, M, tot.p + 3));
         hipLaunchKernelGGL(k_out_sizes, dim3(gb), dim3(CT), 0, s, src, op, sid, gstart.p, ord, M, lrn_flag.p, lrn_rank.p, sz_r.p, sz_p.p, sz_l.p);
         RCQ(scan_u32(s, sz_r.p, off_r.p, M, tot.p));
@@ -695,8 +932,8 @@ int run_impl(cora_hip_collapse *c)
         if (hc.name_overflow) return fail(19, "a read-mer's name exceeds 4 GiB");
         DBuf<u8> d_r, d_p, d_l;
         RCQ(d_r.alloc(totals[0] + 16)); RCQ(d_p.alloc(totals[1] + 16)); RCQ(d_l.alloc(totals[2] + 16));
-        hipLaunchKernelGGL(k_out_write, dim3(gb), dim3(CT), 0, s, src, op, sid, gstart.p, ord, M, lrn_flag.p, lrn_rank.p, off_r.p, off_p.p, off_l.p,
-                           d_r.p, d_p.p, d_l.p);
+        LAUNCH_W(k_out_write, dim3(gb), dim3(CT), s, src, op, sid, gstart.p, ord, M, lrn_flag.p, lrn_rank.p, off_r.p, off_p.p, off_l.p,
+                 sz_r.p, sz_p.p, sz_l.p, d_r.p, d_p.p, d_l.p);
         HIPQ(hipEventRecord(ev[5], s));
         RCQ(c->out_r.reserve(totals[0] + 1)); RCQ(c->out_p.reserve(totals[1] + 1)); RCQ(c->out_l.reserve(totals[2] + 1));
         if (totals[0]) HIPQ(hipMemcpyAsync(c->out_r.p, d_r.p, totals[0], hipMemcpyDeviceToHost, s));

@@ -207,3 +207,39 @@ def workload_repeat_rich(seed: int = 5, total_len: int = 100_000_000, max_copies
 def ensure_dir(p: str) -> str:
     os.makedirs(p, exist_ok=True)
     return p
+
+
+def fastq_image(seed: int, ref: np.ndarray, n: int, L: int, dup_frac: float = 0.25, novel_frac: float = 0.1,
+                mut_frac: float = 0.15, n_frac: float = 0.01) -> bytes:
+    """n reads of length L as one FASTQ image (read side of the pipeline, /root/reference/collapse.cpp:923-935 reads four
+    lines per record): stretches of ``ref`` (an N-free uint8 ASCII array) in either strand, a share of them taken from a
+    small pool of positions (heavy duplicates), a share with one substitution, a share with one N, and a share of random
+    reads that are not in the reference.  Headers are ``@r`` + nine digits, qualities ``I``."""
+    rs = np.random.RandomState(seed)
+    pos = rs.randint(0, len(ref) - L + 1, size=n).astype(np.int64)
+    pool = rs.randint(0, len(ref) - L + 1, size=max(1, n // 200)).astype(np.int64)
+    kind = rs.random_sample(n)
+    dup = kind < dup_frac
+    pos[dup] = pool[rs.randint(0, len(pool), size=int(dup.sum()))]
+    reads = ref[pos[:, None] + np.arange(L)[None, :]]
+    novel = kind > 1.0 - novel_frac
+    reads[novel] = _ACGT[rs.randint(0, 4, size=(int(novel.sum()), L)).astype(np.uint8)]
+    mut = np.nonzero((kind >= dup_frac) & (kind < dup_frac + mut_frac))[0]
+    at = rs.randint(0, L, size=len(mut))
+    code = (np.searchsorted(_ACGT, reads[mut, at]) + rs.randint(1, 4, size=len(mut))) & 3
+    reads[mut, at] = _ACGT[code]
+    withn = np.nonzero(rs.random_sample(n) < n_frac)[0]
+    reads[withn, rs.randint(0, L, size=len(withn))] = ord("N")
+    flip = np.nonzero(rs.randint(0, 2, size=n))[0]
+    reads[flip] = _COMP[reads[flip, ::-1]]
+    rec = np.empty((n, 12 + L + 1 + 2 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for k in range(9):
+        rec[:, 10 - k] = 48 + (idx // 10 ** k) % 10
+    rec[:, 11] = 10
+    rec[:, 12:12 + L] = reads
+    rec[:, 12 + L] = 10; rec[:, 13 + L] = ord("+"); rec[:, 14 + L] = 10
+    rec[:, 15 + L:15 + 2 * L] = ord("I")
+    rec[:, 15 + 2 * L] = 10
+    return rec.tobytes()
