@@ -30,6 +30,7 @@ struct Src {               // where read-mers live: both sides 2-bit packed, 32 
     const u64 *rpk;        // the reads, sequence after sequence (k_reads_pack): read-mer idx starts at base idx * R
     const u32 *rbad;       // one bit per read base, MSB first: the base is an N (its code in rpk is 0)
     u64 rpk_words;
+    u64 *rsw;              // one bit per read-mer of the input: its canonical form is the reverse complement (written by k_read_keys)
     u64 G;                 // ids below G are reference positions; id - G = running read-mer index
     u32 R, splits;
 };
@@ -359,9 +360,13 @@ template <int W>
 __global__ __launch_bounds__(CT) void k_read_keys(Src s, u64 n_items, u64 out_base, u64 *__restrict__ key, u32 *__restrict__ id)
 {
     const u64 idx = (u64)blockIdx.x * CT + threadIdx.x;
-    if (idx >= n_items) return;
+    const bool live = idx < n_items;
     Mer<W> m;
-    canon<W>(s, (u32)(s.G + idx), m);
+    m.sw = 0;
+    if (live) canon<W>(s, (u32)(s.G + idx), m);
+    const u64 bal = __ballot(m.sw != 0);
+    if ((threadIdx.x & 63) == 0) s.rsw[idx >> 6] = bal;
+    if (!live) return;
     key[out_base + idx] = fnv_of<W>(m, s.R); id[out_base + idx] = (u32)(s.G + idx);
 }
 
@@ -476,9 +481,9 @@ __device__ __forceinline__ u32 put_dec(P dst, u64 v)
 template <int W>
 __device__ __forceinline__ u64 id_value(const Src &s, const u32 *__restrict__ id, u32 q, bool in_ref, u32 ref_dir)
 {
-    const u32 x = id[q];
-    const u32 sw = strand_of<W>(s, x);
-    return 2 * ((u64)x - s.G) + (in_ref ? (sw != ref_dir) : sw);
+    const u64 idx = (u64)id[q] - s.G;                                   // always a read-mer of the input
+    const u32 sw = (u32)(s.rsw[idx >> 6] >> (idx & 63)) & 1u;
+    return 2 * idx + (in_ref ? (sw != ref_dir) : sw);
 }
 
 __device__ __forceinline__ u32 lrn_len(u64 number, u32 D)
@@ -702,10 +707,12 @@ struct cora_hip_collapse {
     HBuf<u8> out_r, out_p, out_l;
     u64 n_r = 0, n_p = 0, n_l = 0;
     SortScratch sort_scratch;
+    DevPool pool;                             // device memory of a run, kept for the next run of this object
     cora_hip_collapse_stats st;
     ~cora_hip_collapse()
     {
         sort_scratch.release();
+        pool.destroy();
         if (ref_job) cora_hip_job_destroy(ref_job);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -773,10 +780,10 @@ int run_impl(cora_hip_collapse *c)
     }
     const u64 n_rd = n_reads * stride;                      // sequence lines
     const u64 n_items = n_rd * splits;
-    DBuf<u64> seq_at, rpk;
+    DBuf<u64> seq_at, rpk, rsw;
     DBuf<u32> rbad;
     const u64 rpk_words = (n_items * R + 31) / 32 + 12;
-    RCQ(seq_at.alloc(n_rd + 1)); RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words));
+    RCQ(seq_at.alloc(n_rd + 1)); RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8));
     {
         u64 first = 0;
         for (size_t f = 0; f < c->files.size(); f++) {
@@ -821,7 +828,7 @@ int run_impl(cora_hip_collapse *c)
 
     // ---- records ----
     Src src;
-    src.pk = rj ? rj->pk.p : nullptr; src.pk_words = rj ? rj->pk.n : 0; src.rpk = rpk.p; src.rbad = rbad.p; src.rpk_words = rpk_words;
+    src.pk = rj ? rj->pk.p : nullptr; src.pk_words = rj ? rj->pk.n : 0; src.rpk = rpk.p; src.rbad = rbad.p; src.rpk_words = rpk_words; src.rsw = rsw.p;
     src.G = G; src.R = R; src.splits = splits;
     DBuf<u64> key, tkey;
     DBuf<u32> id, tid;
@@ -844,6 +851,7 @@ int run_impl(cora_hip_collapse *c)
     SortArrays ka, kt;
     ka.a = key.p; ka.c = id.p; kt.a = tkey.p; kt.c = tid.p;
     SortTiming timing;
+    timing.enabled = true;
     if (N && radix_sort(s, ka, kt, N, 0, hash_bits, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
     u64 *skey = ka.a;
     u32 *sid = ka.c;
@@ -1013,7 +1021,7 @@ int cora_hip_collapse_add_reads(cora_hip_collapse *c, const uint8_t *fastq, size
 int cora_hip_collapse_run(cora_hip_collapse *c)
 {
     if (!c) return fail(10, "null argument");
-    PoolScope no_pool(nullptr);
+    PoolScope scope(&c->pool);
     return run_impl(c);
 }
 

@@ -21,22 +21,26 @@ D = 5
 
 
 def run(fq, with_ref=True, split="FULL", rounds=3):
+    """Best of `rounds` runs of ONE collapse object (the first run also pays for the device allocations)."""
+    c = ccol.Collapse(D, L, "SINGLE", split, "GENERIC")
+    if with_ref:
+        c.set_reference(fasta)
+    c.add_reads(fq)
     best = None
-    for _ in range(rounds):
-        c = ccol.Collapse(D, L, "SINGLE", split, "GENERIC")
-        if with_ref:
-            c.set_reference(fasta)
-        c.add_reads(fq)
+    for i in range(rounds):
         t0 = time.perf_counter()
         c.run()
         wall = (time.perf_counter() - t0) * 1e3
         st = c.stats()
         st["wall_run"] = wall
-        outs = c.outputs()
-        c.close()
-        if best is None or st["ms_device"] < best[0]["ms_device"]:
-            best = (st, outs)
-    return best
+        if i == 0:
+            first = st["ms_device"]
+        if best is None or st["ms_device"] < best["ms_device"]:
+            best = st
+    best["first_run_ms_device"] = first
+    outs = c.outputs()
+    c.close()
+    return best, outs
 
 
 t0 = time.perf_counter()
@@ -48,8 +52,8 @@ for split in (("FULL",) if one else ("FULL", "HALF")):
     recs = st["ref_windows"] + st["read_mers"]
     print("%s: %d reference windows + %d read-mers -> %d distinct, %d printed; outputs %d / %d / %d B" % (
         split, st["ref_windows"], st["read_mers"], st["distinct"], st["printed"], len(outs[0]), len(outs[1]), len(outs[2])), flush=True)
-    print("   device %.2f ms (parse %.2f, keys %.2f, group %.2f, order %.2f, text %.2f), run() wall %.1f ms: %.2f G records/s, %.1f M reads/s; sort scatter %.2f ms in %d launches = %.2f TB/s" % (
-        st["ms_device"], st["ms_parse"], st["ms_keys"], st["ms_group"], st["ms_order"], st["ms_text"], st["wall_run"], recs / st["ms_device"] / 1e6,
+    print("   device %.2f ms (first run %.2f; parse %.2f, keys %.2f, group %.2f, order %.2f, text %.2f), run() wall %.1f ms: %.2f G records/s, %.1f M reads/s; sort scatter %.2f ms in %d launches = %.2f TB/s" % (
+        st["ms_device"], st["first_run_ms_device"], st["ms_parse"], st["ms_keys"], st["ms_group"], st["ms_order"], st["ms_text"], st["wall_run"], recs / st["ms_device"] / 1e6,
         st["reads"] / st["ms_device"] / 1e3, st["ms_sort_scatter"], st["n_sort_scatter"],
         st["sort_scatter_bytes"] / max(st["ms_sort_scatter"], 1e-9) / 1e9), flush=True)
 if one:
