@@ -686,7 +686,7 @@ __global__ __launch_bounds__(CT) void k_out_write(Src s, OutParams op, const u32
 
 u32 grid_of(u64 n, u32 per) { const u64 g = (n + per - 1) / per; return (u32)(g ? g : 1); }
 
-// kernels over read-mers exist for 4 words (up to 128 bases) and 10 words (up to 320; the reference stops below 300, CL:27)
+// kernels over read-mers exist for 4 words (up to 128 bases) and 10 words (up to 320; the reference's lines end at 298 bases, CL:27)
 #define LAUNCH_W(kernel, grid, block, stream, ...)                                                              \
     do {                                                                                                        \
         if (R <= 128) hipLaunchKernelGGL(kernel<4>, grid, block, 0, stream, __VA_ARGS__);                        \
@@ -977,7 +977,8 @@ int cora_hip_collapse_create(const cora_hip_collapse_params *p, cora_hip_collaps
     if (p->splits < 1 || p->splits > 3) return fail(9, "Split mode unrecognized");                     // CL:584-588
     if (p->mapper < 0 || p->mapper > 3) return fail(19, "mapper mode out of range");
     if (p->digit_len < 2 || p->digit_len > 10) return fail(19, "digit length %d outside 2..10 (CL:32)", p->digit_len);
-    if (p->read_len < p->splits || p->read_len >= 300) return fail(19, "read length %d outside %d..299 (CL:27)", p->read_len, p->splits);
+    // a line of 299 bases no longer fits the reference's fgets(.., 300) with its line end (CL:27, 923-935): its records fall apart there
+    if (p->read_len < p->splits || p->read_len > 298) return fail(19, "read length %d outside %d..298 (CL:27)", p->read_len, p->splits);
     cora_hip_collapse *c = new cora_hip_collapse();
     c->prm = *p;
     c->R = (u32)(p->read_len / p->splits);                                                              // CL:566-583

@@ -96,3 +96,28 @@ def test_oracle_refuses_what_it_does_not_restate(tmp_path):
     assert subprocess.run(args, stderr=subprocess.DEVNULL).returncode == 78
     args[13] = "AA_AC_"
     assert subprocess.run(args, stderr=subprocess.DEVNULL).returncode == 19
+
+
+import make_collapse_seeded as mcs  # noqa: E402
+
+SEEDED = json.load(open(mcs.MANIFEST))
+
+
+def check_seeded(name, outs):
+    want = SEEDED[name]
+    for i, fn in enumerate(("reads", "perfect", "lrn")):
+        assert outs[i] is not None, "%s: no %s file" % (name, fn)
+        assert len(outs[i]) == want["bytes"][i], (name, fn, len(outs[i]), want["bytes"][i])
+        assert hashlib.sha256(outs[i]).hexdigest() == want["sha256"][i], "%s: %s differs from the reference's" % (name, fn)
+
+
+def test_seeded_manifest_covers_every_case():
+    assert sorted(SEEDED) == sorted(mcs.CASES)
+
+
+@pytest.mark.parametrize("name", sorted(mcs.CASES))
+def test_oracle_matches_the_reference_on_seeded_reads(name, tmp_path):
+    """Read-mers of 12 .. 298 bases, many N, long names: the restatement against the real reference's sha256."""
+    outs, r = mcs.run(build_collapse_oracle(), name, str(tmp_path))
+    assert r.returncode == 0, r.stderr[-500:]
+    check_seeded(name, outs)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import helpers
-from test_collapse_oracle import MANIFEST, build_collapse_oracle, check_outputs, mcg
+from test_collapse_oracle import MANIFEST, build_collapse_oracle, check_outputs, check_seeded, mcg, mcs
 from cora_amd import collapse as ccol, hip
 
 pytestmark = pytest.mark.gpu
@@ -55,3 +55,28 @@ def test_forced_hash_collisions_change_nothing(name, bits, monkeypatch):
     outs, st = _run_case(mcg.CASES[name])
     assert st["hash_collisions"] > 0
     check_outputs(name, outs)
+
+
+COLLAPSE_EXE = os.path.join(helpers.ROOT, "cora_amd", "bin", "collapse")
+
+
+@pytest.mark.parametrize("name", sorted(mcs.CASES))
+def test_executable_matches_the_reference_on_seeded_reads(name, tmp_path):
+    """The drop-in executable (the reference's sixteen arguments) on seeded reads whose read-mers span every word count of
+    the packed path (12 .. 298 bases), with many N and names long enough for the long-read-name file."""
+    outs, r = mcs.run(COLLAPSE_EXE, name, str(tmp_path))
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-500:])
+    check_seeded(name, outs)
+    assert os.path.exists(os.path.join(str(tmp_path), name + ".kill"))       # the kill-signal file of CL:2420-2424
+
+
+def test_executable_argument_errors(tmp_path):
+    r = subprocess.run([COLLAPSE_EXE, "x"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0
+    args, _ = mcs.materialize("L64_full", str(tmp_path))
+    bad = list(args); bad[10] = "QUARTER"                                      # split mode (CL:584-588)
+    r = subprocess.run([COLLAPSE_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0
+    bad = list(args); bad[12] = "FRAGMENT"                                     # fragmented mode is refused, not mis-run
+    r = subprocess.run([COLLAPSE_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 19
