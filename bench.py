@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bases", type=int, default=64_000_000, help="reference length (default: chr20-sized)")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="bases of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--collapse-reads", type=int, default=4_000_000, help="reads of the read-side figure printed beside the headline (0 = skip)")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="what N>1 ranks do (see the module text)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = host-staged rehearsal)")
     a = ap.parse_args()
@@ -216,6 +217,33 @@ def main():
                                  "ms_device": round(best["ms_scan"], 3), "image_bytes": int(best["image_bytes"]), "lines": int(best["lines"]),
                                  "GB_per_s_algorithmic": round(2 * best["image_bytes"] / 1e6 / max(best["ms_scan"], 1e-6), 1),
                                  "conforming": int(best["conforming"]), "cpu": cpu}
+            # the read-side row: reads drawn from the bench reference collapsed against it (collapse.cpp, whole-input mode)
+            if a.collapse_reads > 0:
+                import numpy as np
+                from cora_amd import collapse as ccol
+                img = np.frombuffer(img_bytes, dtype=np.uint8)
+                src = img[np.isin(img, np.frombuffer(b"ACGT", dtype=np.uint8))]      # header and N-run dropped (the header's letters, if any, are a few bases of noise)
+                fq = synth.fastq_image(77, src, a.collapse_reads, 100)
+                del src, img
+                cj = ccol.Collapse(5, 100, "SINGLE", "FULL", "GENERIC")
+                cj.set_reference(img_bytes)
+                cj.add_reads(fq)
+                best = None
+                for _ in range(3):
+                    cj.run()
+                    cs = cj.stats()
+                    if best is None or cs["ms_device"] < best["ms_device"]:
+                        best = cs
+                cj.close()
+                recs = best["ref_windows"] + best["read_mers"]
+                out["collapse"] = {"what": "read-mer collapsing of %d synthetic 100-base reads against the bench reference (collapse.cpp whole-input mode): three output "
+                                           "files as bytes; FASTQ and FASTA images resident in HBM when timed" % a.collapse_reads,
+                                   "ms_device": round(best["ms_device"], 3), "records": int(recs), "G_records_per_s": round(recs / best["ms_device"] / 1e6, 3),
+                                   "M_reads_per_s": round(best["reads"] / best["ms_device"] / 1e3, 1),
+                                   "stage_ms": {k: round(best[k], 3) for k in ("ms_parse", "ms_keys", "ms_group", "ms_order", "ms_text")},
+                                   "distinct": int(best["distinct"]), "printed": int(best["printed"]), "output_bytes": int(best["reads_bytes"] + best["perfect_bytes"] + best["lrn_bytes"]),
+                                   "sort_scatter_TB_per_s": round(best["sort_scatter_bytes"] / max(best["ms_sort_scatter"], 1e-9) / 1e9, 2),
+                                   "cpu": "profiles/collapse_bench.py times oracle/collapse_oracle on a quarter-size sample (same bytes required)"}
         print(json.dumps(out), flush=True)
     job.close()
     if world > 1:
