@@ -33,3 +33,9 @@ if [ -f "$csrc" ]; then
   wait
   echo "built $here/_ref/collapse and collapse_L"
 fi
+# fastqSplit (signal-keyed partitioning of the reads): /root/reference/makefile:12-13 minus -march=native
+fsrc="${CORA_REFERENCE:-/root/reference}/fastqSplit.cpp"
+if [ -f "$fsrc" ]; then
+  g++ -static -O3 -w -o "$here/_ref/fastqSplit" "$fsrc" 2>/dev/null
+  echo "built $here/_ref/fastqSplit"
+fi
