@@ -15,12 +15,12 @@
 // The hash (tr1::hash<string> = FNV-1a 64) and B come from libstdc++ itself on the host (collapse_host.cpp).
 // Integer / byte work; the heavy parts are the sequential FNV over R bases per record (ALU) and the sorts (HBM).
 #include "job_internal.hpp"
+#include "reads_common.hpp"
 
 using namespace cora;
 
 namespace {
 
-constexpr int CT = 256;
 constexpr u64 FNV_BASIS = 14695981039346656037ull, FNV_PRIME = 1099511628211ull;
 constexpr u32 ACGT_PACKED = 0x54474341u;       // 'A' 'C' 'G' 'T' by 2-bit code
 
@@ -38,25 +38,6 @@ struct Src {               // where read-mers live: both sides 2-bit packed, 32 
 struct CollapseCounters {
     unsigned long long bad_read_bytes, n_mixed, n_owners, n_lrn, name_overflow;
 };
-
-__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *lds, u32 *total)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    u32 x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        u32 y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) lds[wv] = x;
-    __syncthreads();
-    u32 base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < CT / 64; w++) { u32 t = lds[w]; if (w < wv) base += t; tot += t; }
-    if (total) *total = tot;
-    __syncthreads();
-    return base + x - v;
-}
 
 // ------------------------------------------------------------------ a read-mer as words
 // The canonical form (CL:97-122: the reverse complement when it is the lexicographically smaller string, ASCII order
@@ -247,48 +228,6 @@ __device__ __forceinline__ u32 strand_of(const Src &s, u32 id)
     Mer<W> a;
     canon<W>(s, id, a);
     return a.sw;
-}
-
-// ------------------------------------------------------------------ FASTQ: sequence line of every record
-__global__ __launch_bounds__(CT) void k_nl_count(const u8 *__restrict__ img, u64 n, u32 *__restrict__ blk)
-{
-    __shared__ u32 lds[4];
-    const u64 at = ((u64)blockIdx.x * CT + threadIdx.x) * 16;
-    u32 c = 0;
-    if (at < n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(img + at);
-        const u32 w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 16; i++) c += (at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n';
-    }
-    u32 tot;
-    block_excl_scan(c, lds, &tot);
-    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
-}
-
-// newline number j of the file (0-based) with j % 4 == 0 ends a header line: the sequence of record j / 4 starts behind it
-__global__ __launch_bounds__(CT) void k_fq_emit(const u8 *__restrict__ img, u64 n, const u64 *__restrict__ blk_off, u64 file_off,
-                                                u64 *__restrict__ seq_at, u64 first_read, u32 stride, u64 n_records)
-{
-    __shared__ u32 lds[4];
-    const u64 at = ((u64)blockIdx.x * CT + threadIdx.x) * 16;
-    u32 c = 0;
-    u32 w[4] = {0, 0, 0, 0};
-    if (at < n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(img + at);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-#pragma unroll
-        for (int i = 0; i < 16; i++) c += (at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n';
-    }
-    u64 j = blk_off[blockIdx.x] + block_excl_scan(c, lds, nullptr);
-    if (!c) return;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if ((at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n') {
-            if ((j & 3) == 0 && (j >> 2) < n_records) seq_at[(first_read + (j >> 2)) * stride] = file_off + at + i + 1;
-            j++;
-        }
-    }
 }
 
 // The first RL = splits * R bases of every sequence line, packed one read behind the other: one thread per 32 bases.
@@ -684,7 +623,6 @@ __global__ __launch_bounds__(CT) void k_out_write(Src s, OutParams op, const u32
     }
 }
 
-u32 grid_of(u64 n, u32 per) { const u64 g = (n + per - 1) / per; return (u32)(g ? g : 1); }
 
 // kernels over read-mers exist for 4 words (up to 128 bases) and 10 words (up to 320; the reference's lines end at 298 bases, CL:27)
 #define LAUNCH_W(kernel, grid, block, stream, ...)                                                              \
@@ -702,8 +640,7 @@ struct cora_hip_collapse {
     hipStream_t stream = nullptr;
     cora_hip_job *ref_job = nullptr;          // holds the packed reference (pk, bad, contig table)
     std::vector<u8> h_rd;                     // FASTQ images, 16-byte aligned starts
-    struct File { u64 off, bytes; };
-    std::vector<File> files;                  // in list order: sample 0 mate 1, sample 0 mate 2, ...
+    std::vector<ReadFile> files;                  // in list order: sample 0 mate 1, sample 0 mate 2, ...
     HBuf<u8> out_r, out_p, out_l;
     u64 n_r = 0, n_p = 0, n_l = 0;
     SortScratch sort_scratch;
@@ -719,15 +656,6 @@ struct cora_hip_collapse {
 };
 
 namespace {
-
-int scan_u32(hipStream_t s, const u32 *in, u64 *out, u64 n, u64 *total_dev)
-{
-    DBuf<u64> tmp;
-    RCQ(tmp.alloc(scan_scratch_elems(n)));
-    if (exclusive_scan_u32_to_u64(s, in, out, n, tmp.p, total_dev)) return fail(100, "scan launch failed");
-    HIPQ(hipStreamSynchronize(s));            // tmp is released on return
-    return 0;
-}
 
 int run_impl(cora_hip_collapse *c)
 {
@@ -747,54 +675,19 @@ int run_impl(cora_hip_collapse *c)
     HIPQ(hipMemsetAsync(ctr.p, 0, sizeof(CollapseCounters), s));
 
     // ---- the reads: images to HBM, sequence line of every record ----
-    const u32 stride = prm.paired ? 2u : 1u;
-    if (c->files.size() % stride) return fail(6, "paired input needs two files per sample");
     DBuf<u8> rd;
     RCQ(rd.alloc(c->h_rd.size() + 1024));
     HIPQ(hipMemsetAsync(rd.p + c->h_rd.size(), 0, 1024, s));
     if (!c->h_rd.empty()) HIPQ(hipMemcpyAsync(rd.p, c->h_rd.data(), c->h_rd.size(), hipMemcpyHostToDevice, s));
     HIPQ(hipEventRecord(ev[0], s));
-    std::vector<u64> file_records(c->files.size());
-    std::vector<DBuf<u64> *> blk_offs;
-    u64 n_reads = 0;                                        // records over all samples (pairs count once here)
-    struct Guard { std::vector<DBuf<u64> *> &v; ~Guard() { for (auto *p : v) delete p; } } g2{blk_offs};
-    for (size_t f = 0; f < c->files.size(); f++) {
-        const auto &fl = c->files[f];
-        const u32 blocks = grid_of(fl.bytes, CT * 16);
-        DBuf<u32> blk;
-        RCQ(blk.alloc(blocks));
-        DBuf<u64> *bo = new DBuf<u64>();
-        blk_offs.push_back(bo);
-        RCQ(bo->alloc(blocks));
-        hipLaunchKernelGGL(k_nl_count, dim3(blocks), dim3(CT), 0, s, rd.p + fl.off, fl.bytes, blk.p);
-        RCQ(scan_u32(s, blk.p, bo->p, blocks, tot.p));
-        u64 n_nl = 0;
-        HIPQ(hipMemcpyAsync(&n_nl, tot.p, 8, hipMemcpyDeviceToHost, s));
-        HIPQ(hipStreamSynchronize(s));
-        const u64 lines = n_nl + ((fl.bytes && c->h_rd[fl.off + fl.bytes - 1] != '\n') ? 1 : 0);
-        if (lines % 4) return fail(7, "input file %zu holds %llu lines: not a multiple of 4 (FASTQ records are read 4 lines at a time, CL:923-935)", f + 1, (unsigned long long)lines);
-        file_records[f] = lines / 4;
-        if (prm.paired && (f & 1) && file_records[f] != file_records[f - 1])
-            return fail(7, "mate files of sample %zu hold %llu and %llu records", f / 2 + 1, (unsigned long long)file_records[f - 1], (unsigned long long)file_records[f]);
-        if (!prm.paired || (f & 1)) n_reads += file_records[f];
-    }
-    const u64 n_rd = n_reads * stride;                      // sequence lines
-    const u64 n_items = n_rd * splits;
     DBuf<u64> seq_at, rpk, rsw;
     DBuf<u32> rbad;
+    u64 n_rd = 0;                                           // sequence lines
+    RCQ(locate_sequence_lines(s, rd.p, c->h_rd, c->files, prm.paired != 0, tot.p, seq_at, n_rd));
+    const u64 n_items = n_rd * splits;
     const u64 rpk_words = (n_items * R + 31) / 32 + 12;
-    RCQ(seq_at.alloc(n_rd + 1)); RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8));
-    {
-        u64 first = 0;
-        for (size_t f = 0; f < c->files.size(); f++) {
-            const auto &fl = c->files[f];
-            const u32 mate = prm.paired ? (u32)(f & 1) : 0u;
-            hipLaunchKernelGGL(k_fq_emit, dim3(grid_of(fl.bytes, CT * 16)), dim3(CT), 0, s, rd.p + fl.off, fl.bytes, blk_offs[f]->p, fl.off,
-                               seq_at.p + mate, first, stride, file_records[f]);
-            if (!prm.paired || (f & 1)) first += file_records[f];
-        }
-        hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, rd.p, seq_at.p, n_rd, R * splits, rpk.p, rbad.p, rpk_words, ctr.p);
-    }
+    RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8));
+    hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, rd.p, seq_at.p, n_rd, R * splits, rpk.p, rbad.p, rpk_words, ctr.p);
 
     // ---- the reference: packed by the table builder's kernel ----
     u64 G = 0, NW = 0, other_letters = 0;
@@ -1010,7 +903,7 @@ int cora_hip_collapse_set_reference(cora_hip_collapse *c, const cora_hip_fasta *
 int cora_hip_collapse_add_reads(cora_hip_collapse *c, const uint8_t *fastq, size_t bytes)
 {
     if (!c || (!fastq && bytes)) return fail(5, "null argument");
-    cora_hip_collapse::File f;
+    ReadFile f;
     f.off = (c->h_rd.size() + 15) & ~(size_t)15;
     f.bytes = bytes;
     c->h_rd.resize(f.off + bytes);

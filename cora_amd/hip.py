@@ -30,6 +30,8 @@ EXPORTS = [
     "cora_hip_fasta_destroy", "cora_hip_job_set_reference_fasta",
     "cora_hip_collapse_table_geometry", "cora_hip_collapse_create", "cora_hip_collapse_set_reference", "cora_hip_collapse_add_reads",
     "cora_hip_collapse_run", "cora_hip_collapse_outputs", "cora_hip_collapse_get_stats", "cora_hip_collapse_destroy",
+    "cora_hip_fqsplit_parse_signals", "cora_hip_fqsplit_create", "cora_hip_fqsplit_add_reads", "cora_hip_fqsplit_run",
+    "cora_hip_fqsplit_group", "cora_hip_fqsplit_get_stats", "cora_hip_fqsplit_destroy",
 ]
 
 

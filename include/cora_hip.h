@@ -281,6 +281,43 @@ int cora_hip_collapse_outputs(const cora_hip_collapse *c, const uint8_t **reads,
 int cora_hip_collapse_get_stats(const cora_hip_collapse *c, cora_hip_collapse_stats *out);
 void cora_hip_collapse_destroy(cora_hip_collapse *c);
 
+/* ---- the read side, before collapse: `fastqSplit`, signal-keyed partitioning of the reads ----
+ * FS = /root/reference/fastqSplit.cpp.  Replaces its main() between "arguments and signals read" and "fragment files
+ * written" (FS:341-867): every read-mer of the input goes, as 8 bytes of 2 x its running number + its characters
+ * (FS:157-173), to the fragment file of the group its signal belongs to, in input order. */
+typedef struct cora_hip_fqsplit cora_hip_fqsplit;   /* opaque */
+
+typedef struct cora_hip_fqsplit_params {
+    int32_t read_len;       /* argv[2] */
+    int32_t splits;         /* argv[5]: 1 SINGLE / PAIRED, 2 SPLIT_*, 3 THREEWAY_* (read-mer length = read_len / splits) */
+    int32_t paired;         /* argv[5]: 0 *SINGLE, 1 *PAIRED (files are then added as mate 1, mate 2 per sample) */
+    int32_t signal_size;    /* 2: first and last base of a read-mer; 4: first two and last two (FS:131-139) */
+    int32_t n_groups;       /* fragment files <prefix>.frag0 .. (FS:341-347), 1..255 */
+    uint8_t group_of[628];  /* group of a signal: index ((s0 * 5 + s1) * 5 + s2) * 5 + s3, or s0 * 5 + s1 for 2-character signals,
+                               with N 0, A 1, C 2, G 3, T 4 (FS:21-40); signals the file does not list are group 0 (FS:16-17) */
+} cora_hip_fqsplit_params;
+
+typedef struct cora_hip_fqsplit_stats {
+    uint64_t reads, read_mers, record_bytes, output_bytes, image_bytes;
+    float ms_parse, ms_classify, ms_order, ms_write, ms_device, ms_total;   /* HIP events; ms_total = wall of the run call */
+} cora_hip_fqsplit_stats;
+
+/* Host only: signal_size, n_groups and group_of from the text of the signals file (argv[1], FS:54-129; written by
+ * cora.cpp:335-390).  Status 7 for what the reference exits 7 on or asserts against. */
+int cora_hip_fqsplit_parse_signals(const char *text, size_t bytes, cora_hip_fqsplit_params *out);
+int cora_hip_fqsplit_create(const cora_hip_fqsplit_params *params, cora_hip_fqsplit **out);
+/* One FASTQ file image (host memory, copied), in the order of the list file (argv[3]): per sample the reads file, then, if
+ * paired, the mates file.  Records are four lines (the reference finds them by skipping 2 x read_len + 5 bytes and then
+ * to the next line end, FS:257-283: the same records when the third line is a bare '+').  Status 78 for a sequence line
+ * shorter than read_len or a signal byte outside A C G T N (the reference copies across the line end / indexes outside
+ * its tables there). */
+int cora_hip_fqsplit_add_reads(cora_hip_fqsplit *s, const uint8_t *fastq, size_t bytes);
+int cora_hip_fqsplit_run(cora_hip_fqsplit *s);
+/* Bytes of <prefix>.frag<group>; valid until the next run or destroy. */
+int cora_hip_fqsplit_group(const cora_hip_fqsplit *s, int32_t group, const uint8_t **bytes, size_t *n);
+int cora_hip_fqsplit_get_stats(const cora_hip_fqsplit *s, cora_hip_fqsplit_stats *out);
+void cora_hip_fqsplit_destroy(cora_hip_fqsplit *s);
+
 /* ---- stage-level entry points (used by the parity tests and the benchmark) ---- */
 
 /* Stable LSD radix sort of n records on device memory, keyed on bits

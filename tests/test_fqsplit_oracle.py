@@ -50,3 +50,32 @@ def test_oracle_matches_the_reference(name, tmp_path):
     outs, r = mfg.run(build_fqsplit_oracle(), name, str(tmp_path))
     assert r.returncode == 0, r.stderr[-500:]
     check_fragments(name, outs)
+
+
+def test_signal_table_of_the_library_host_only():
+    """cora_hip_fqsplit_parse_signals (no GPU needed): the table it fills sends every signal where the signals file says,
+    N-holding signals to the last group, unlisted ones to group 0 (fastqSplit.cpp:54-129, 16-17)."""
+    from cora_amd import fastqsplit
+    sym = {"N": 0, "A": 1, "C": 2, "G": 3, "T": 4}
+    for n, size in ((3, 4), (8, 4), (1, 4), (2, 2), (10, 2)):
+        text = mfg.frag_text(n, size)
+        p = fastqsplit.parse_signals(text.encode())
+        assert (p.signal_size, p.n_groups) == (size, n)
+        want = [0] * (5 ** size)
+        for g, ln in enumerate(text.split("\n")[1:1 + n]):
+            if ln.startswith("N_"):
+                for v in range(5 ** size):
+                    digits = [(v // 5 ** k) % 5 for k in range(size)]
+                    if 0 in digits:
+                        want[v] = g
+                ln = ln[2:]
+            for s in filter(None, ln.split("_")):
+                v = 0
+                for ch in s:
+                    v = v * 5 + sym[ch]
+                want[v] = g
+        assert list(p.group_of[:5 ** size]) == want
+    with pytest.raises(Exception):
+        fastqsplit.parse_signals(b"2 3\nAC_GT_\n")            # signal size 3: the reference exits 7
+    with pytest.raises(Exception):
+        fastqsplit.parse_signals(b"1 2\nAC_G\n")              # not a whole number of signals: the reference asserts
