@@ -244,6 +244,25 @@ def main():
                                    "distinct": int(best["distinct"]), "printed": int(best["printed"]), "output_bytes": int(best["reads_bytes"] + best["perfect_bytes"] + best["lrn_bytes"]),
                                    "sort_scatter_TB_per_s": round(best["sort_scatter_bytes"] / max(best["ms_sort_scatter"], 1e-9) / 1e9, 2),
                                    "cpu": "profiles/collapse_bench.py times oracle/collapse_oracle on a quarter-size sample (same bytes required)"}
+                # the row before it: the same reads partitioned into 8 fragment files by their 4-character signals (fastqSplit.cpp)
+                sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+                from cora_amd import fastqsplit
+                import make_fqsplit_golden as mfg
+                fsj = fastqsplit.FastqSplit(mfg.frag_text(8, 4).encode(), 100, "SINGLE")
+                fsj.add_reads(fq)
+                best = None
+                for _ in range(3):
+                    fsj.run()
+                    fst = fsj.stats()
+                    if best is None or fst["ms_device"] < best["ms_device"]:
+                        best = fst
+                fsj.close()
+                out["fastq_split"] = {"what": "the same %d reads partitioned into 8 fragment files by 4-character signals (fastqSplit.cpp, mode SINGLE): files as bytes "
+                                              "in host memory; FASTQ image resident in HBM when timed" % a.collapse_reads,
+                                      "ms_device": round(best["ms_device"], 3), "M_reads_per_s": round(best["reads"] / best["ms_device"] / 1e3, 1),
+                                      "stage_ms": {k: round(best[k], 3) for k in ("ms_parse", "ms_classify", "ms_order", "ms_write")},
+                                      "image_bytes": int(best["image_bytes"]), "output_bytes": int(best["output_bytes"]),
+                                      "cpu": "profiles/fqsplit_bench.py times oracle/fastqsplit_oracle on the same input (same bytes required)"}
         print(json.dumps(out), flush=True)
     job.close()
     if world > 1:
