@@ -1,8 +1,9 @@
 /*
  * collapse_oracle.c -- TEST INFRASTRUCTURE ONLY (checker for tests/, smoke() and bench.py's cpu_baseline leg).
  *
- * Plain-C sequential restatement of CORA's `collapse` (/root/reference/collapse.cpp, CL below) in its whole-input
- * run mode (argv[13] = NONE, the form `cora search` issues when reads are not fragmented, cora.cpp:1674-1692):
+ * Plain-C sequential restatement of CORA's `collapse` (/root/reference/collapse.cpp, CL below): its whole-input run mode
+ * (argv[13] = NONE, the form `cora search` issues when reads are not fragmented, cora.cpp:1674-1692) and its fragmented
+ * mode (argv[13] = the signals of one group, argv[1] = that group's fragment file written by fastqSplit, cora.cpp:1733-1760):
  * every read-mer of the reference and of the reads is reduced to the lexicographically smaller of itself and its
  * reverse complement (CL:97-122, 125-246), identical read-mers are collapsed (CL:640-643 hash map), every read-mer of
  * the input gets an encoded id (CL:276-289: base-94 digits of 2 * running index + direction), and three text files
@@ -116,7 +117,38 @@ static void bad_byte(const char *what, int c) { fprintf(stderr, "%s holds byte 0
 
 static uint64_t item_index;        /* running index of read-mers over the whole input (CL:276-289, 884-889) */
 
+/* fragmented run mode (argv[13] != NONE): the signals of this run's group (CL:405-488) */
+static char frag_sig[1000][4]; static int n_frag_sig, frag_len;
+
+static void setup_fragmentation(const char *text, int len)                  /* CL:414-462 */
+{
+    if (text[0] == 'N') text += strlen(text) >= 2 ? 2 : strlen(text);       /* nFLAG is set and never read */
+    const size_t n = strlen(text);
+    if (n % (size_t)(len + 1)) { fprintf(stderr, "fragmentation signals: not a whole number of signals\n"); exit(19); }   /* the reference asserts */
+    n_frag_sig = (int)(n / (size_t)(len + 1));
+    if (n_frag_sig > 1000) { fprintf(stderr, "more than 1000 fragmentation signals (CL:410)\n"); exit(19); }
+    for (int i = 0; i < n_frag_sig; i++) memcpy(frag_sig[i], text + (size_t)(len + 1) * i, (size_t)len);
+    frag_len = len;
+}
+
+static int frag_included(const char *w)                                       /* CL:464-488 on a window's first / last bases */
+{
+    if (!frag_len) return 1;
+    char sig[4];
+    if (frag_len == 2) { sig[0] = w[0]; sig[1] = w[R - 1]; }
+    else { sig[0] = w[0]; sig[1] = w[1]; sig[2] = w[R - 2]; sig[3] = w[R - 1]; }
+    for (int i = 0; i < n_frag_sig; i++) if (!memcmp(frag_sig[i], sig, (size_t)frag_len)) return 1;
+    return 0;
+}
+
+static void add_readmer_coded(const char *s, uint64_t code);
+
 static void add_readmer(const char *s)
+{
+    add_readmer_coded(s, 2 * item_index);
+}
+
+static void add_readmer_coded(const char *s, uint64_t code)
 {
     char key[MAXLINE + 1];
     for (int i = 0; i < R; i++) if (!comp(s[i])) bad_byte("a read", s[i]);
@@ -127,7 +159,7 @@ static void add_readmer(const char *s)
     if (created) { nd->ref_code = 0; nd->ref_dir = -1; }
     else if (nd->ref_dir != -1) flag = sw != nd->ref_dir;                    /* CL:963-968 */
     if (n_ids == cap_ids) { cap_ids = cap_ids ? cap_ids * 2 : 1024; id_val = (uint64_t *)realloc(id_val, cap_ids * 8); id_next = (uint32_t *)realloc(id_next, cap_ids * 4); }
-    id_val[n_ids] = 2 * item_index + (uint64_t)flag; id_next[n_ids] = 0;
+    id_val[n_ids] = code + (uint64_t)flag; id_next[n_ids] = 0;
     if (nd->count == 0) nd->id_head = (uint32_t)n_ids + 1; else id_next[nd->id_tail - 1] = (uint32_t)n_ids + 1;
     nd->id_tail = (uint32_t)n_ids + 1;
     n_ids++; nd->count++;
@@ -172,7 +204,7 @@ int main(int argc, char **argv)
     const int chr_short = argc == 18;
     const unsigned invalid_code = chr_short ? 65531u : 251u;                 /* CL:62-66 */
     uint64_t lrn_count = (uint64_t)atoi(argv[16]);
-    if (strcmp(argv[13], "NONE") != 0) { fprintf(stderr, "only the whole-input run mode (argv[13] = NONE) is restated\n"); return 19; }
+    const int fragmented = strcmp(argv[13], "NONE") != 0;
     const int input_len = atoi(argv[6]);
     int splits;
     if (!strcmp(argv[11], "FULL")) splits = 1; else if (!strcmp(argv[11], "HALF")) splits = 2; else if (!strcmp(argv[11], "THREEWAY")) splits = 3;
@@ -187,6 +219,12 @@ int main(int argc, char **argv)
     const int D = atoi(argv[2]);
     if (D < 1 || D > 10) { fprintf(stderr, "digit length out of range\n"); return 19; }
     const int ref_line = atoi(argv[5]);
+    if (fragmented) {                                                        /* CL:542-563 */
+        const int fl = atoi(argv[14]);
+        if (fl != 2 && fl != 4) { printf("fragSignalLen can only be 2 or 4\n"); return 6; }
+        if (R < fl) { fprintf(stderr, "read-mers shorter than the signal\n"); return 19; }
+        setup_fragmentation(argv[13], fl);
+    }
 
     /* ---- reference read-mers (CL:647-711; loader CL:337-402) ---- */
     if (strcmp(argv[4], "NOREF") != 0) {
@@ -224,7 +262,7 @@ int main(int argc, char **argv)
             for (int i = 1; i <= R; i++) { n_count += q[i] == 'N'; other += !comp(q[i]); }
             for (uint32_t i = 1; i <= lim; i++) {
                 if (n_count == 0 && other) garbage_windows++;
-                if (n_count == 0 && !other) {
+                if (n_count == 0 && !other && frag_included(q + i)) {       /* CL:712-835: only this group's windows */
                     const int sw = canonical(q + i, key);
                     int created;
                     node_t *nd = lookup(key, &created);
@@ -238,6 +276,20 @@ int main(int argc, char **argv)
         free(seq); free(len); free(fai); free(ref);
     }
 
+    /* ---- fragmented mode (CL:2173-2284): argv[1] is a fragment file of fastqSplit: records of 8 bytes (number of the
+     *      read-mer x 2) + R characters; whole records only (fread counts items) ---- */
+    if (fragmented) {
+        size_t n;
+        char *b = read_file(argv[1], &n);
+        if (!b) { printf("Binary input file: %s doesn't exist\n", argv[1]); return 5; }
+        const size_t item = 8 + (size_t)R;
+        for (size_t at = 0; at + item <= n; at += item) {
+            uint64_t code;
+            memcpy(&code, b + at, 8);
+            add_readmer_coded(b + at + 8, code);
+        }
+        free(b);
+    } else
     /* ---- reads (CL:861-2171): list file = sample count, then per sample: file [mate file] read count ---- */
     {
         size_t ln;
@@ -271,7 +323,7 @@ int main(int argc, char **argv)
         }
         free(list);
     }
-    { uint64_t lim = 1; for (int i = 0; i < D; i++) lim *= 94; if (item_index && 2 * item_index - 1 >= lim) { fprintf(stderr, "digit length %d cannot number %llu read-mers\n", D, (unsigned long long)item_index); return 19; } }
+    if (!fragmented) { uint64_t lim = 1; for (int i = 0; i < D; i++) lim *= 94; if (item_index && 2 * item_index - 1 >= lim) { fprintf(stderr, "digit length %d cannot number %llu read-mers\n", D, (unsigned long long)item_index); return 19; } }
 
     /* ---- output in the hash map's iteration order (CL:2295-2405) ---- */
     uint32_t *order = (uint32_t *)malloc((n_nodes + 1) * 4);

@@ -121,3 +121,26 @@ def test_oracle_matches_the_reference_on_seeded_reads(name, tmp_path):
     outs, r = mcs.run(build_collapse_oracle(), name, str(tmp_path))
     assert r.returncode == 0, r.stderr[-500:]
     check_seeded(name, outs)
+
+
+import make_collapse_frag_golden as mcf  # noqa: E402
+
+FRAG = json.load(open(mcf.MANIFEST))
+
+
+def check_frag(name, outs):
+    assert all(b is not None for g in outs for b in g), "%s: an output file is missing" % name
+    got = mcf.digest(outs)
+    assert [g["bytes"] for g in got] == [g["bytes"] for g in FRAG[name]], (name, [g["bytes"] for g in got], [g["bytes"] for g in FRAG[name]])
+    assert got == FRAG[name], "%s: files differ from the reference's" % name
+
+
+@pytest.mark.parametrize("name", sorted(mcf.CASES))
+def test_oracles_match_the_reference_in_fragmented_mode(name, tmp_path):
+    """fastqsplit_oracle -> collapse_oracle per group (argv[13] = the group's signals), long-read-name numbers carried along:
+    the per-group files of the real fastqSplit -> collapse chain."""
+    subprocess.check_call(["make", "-C", helpers.ORACLE_DIR, "fastqsplit_oracle"], stdout=subprocess.DEVNULL)
+    outs, codes = mcf.run(os.path.join(helpers.ORACLE_DIR, "fastqsplit_oracle"), build_collapse_oracle(), name, str(tmp_path),
+                          extra=(["L"] if mcf.CASES[name][4] else []))
+    assert set(codes) == {0}, codes
+    check_frag(name, outs)
