@@ -1,4 +1,4 @@
-"""Host-side mirror of CORA's `collapse` (/root/reference/collapse.cpp, whole-input mode) over libcora_hip.so:
+"""Host-side mirror of CORA's `collapse` (/root/reference/collapse.cpp, whole-input and fragmented mode) over libcora_hip.so:
 argument meaning as the reference's argv (input mode, split mode, mapper mode, digit length, LRN offset).  Plumbing for
 tests and the benchmark; the product boundary is the C-ABI (cora_hip_collapse_*) and cora_amd/bin/collapse[_L]."""
 from __future__ import annotations
@@ -35,6 +35,13 @@ class Collapse:
             hip._check(hip.lib().cora_hip_collapse_set_reference(self._h, fa._h))
         finally:
             fa.close()
+
+    def set_fragment(self, signals: str, signal_len: int):
+        """Fragmented mode (collapse.cpp:542-563): `signals` = the group's line of the signals file; the one input added
+        afterwards is that group's fragment file of fastqSplit."""
+        f = hip.lib().cora_hip_collapse_set_fragment
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        hip._check(f(self._h, signals.encode(), signal_len))
 
     def add_reads(self, fastq_image: bytes):
         buf = (C.c_char * max(1, len(fastq_image))).from_buffer_copy(fastq_image or b"\0")

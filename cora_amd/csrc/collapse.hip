@@ -1,5 +1,6 @@
 // collapse.hip -- CORA's read-side read-mer collapsing on gfx950.
-// CL = /root/reference/collapse.cpp, whole-input run mode (argv[13] = NONE, the form cora.cpp:1674-1692 issues).
+// CL = /root/reference/collapse.cpp: whole-input run mode (argv[13] = NONE, the form cora.cpp:1674-1692 issues) and
+// fragmented mode (argv[13] = one group's signals, input = a fragment file of fastqSplit, cora.cpp:1733-1760).
 //
 // What the reference does with one hash map (CL:640-643) is done here with sorts:
 //   * every N-free reference window of R bases (CL:656-711) and every read-mer of the input (reads, mates, splits in
@@ -30,6 +31,7 @@ struct Src {               // where read-mers live: both sides 2-bit packed, 32 
     const u64 *rpk;        // the reads, sequence after sequence (k_reads_pack): read-mer idx starts at base idx * R
     const u32 *rbad;       // one bit per read base, MSB first: the base is an N (its code in rpk is 0)
     u64 rpk_words;
+    const u64 *codes;      // fragmented mode: the number fastqSplit gave each read-mer (2 x its index in the whole input); else null
     u64 *rsw;              // one bit per read-mer of the input: its canonical form is the reverse complement (written by k_read_keys)
     u64 G;                 // ids below G are reference positions; id - G = running read-mer index
     u32 R, splits;
@@ -232,7 +234,8 @@ __device__ __forceinline__ u32 strand_of(const Src &s, u32 id)
 
 // The first RL = splits * R bases of every sequence line, packed one read behind the other: one thread per 32 bases.
 // A byte outside A C G T N (a line end included: the line is shorter than RL) is counted; the run is refused then.
-__global__ __launch_bounds__(CT) void k_reads_pack(const u8 *__restrict__ rd, const u64 *__restrict__ seq_at, u64 n_rd, u32 RL,
+// rec_stride != 0: the input is a fragment file of fastqSplit, line r = the R characters behind the 8-byte number of record r.
+__global__ __launch_bounds__(CT) void k_reads_pack(const u8 *__restrict__ rd, const u64 *__restrict__ seq_at, u64 n_rd, u32 RL, u32 rec_stride,
                                                    u64 *__restrict__ rpk, u32 *__restrict__ rbad, u64 n_words, CollapseCounters *ctr)
 {
     const u64 w = (u64)blockIdx.x * CT + threadIdx.x;
@@ -243,22 +246,38 @@ __global__ __launch_bounds__(CT) void k_reads_pack(const u8 *__restrict__ rd, co
     if (b0 < total) {
         u64 r = b0 / RL;
         u32 o = (u32)(b0 - r * RL);
-        const u8 *p = rd + seq_at[r];
+        const u8 *p = rd + (rec_stride ? r * rec_stride + 8 : seq_at[r]);
         const u32 n = (u32)min((u64)32, total - b0);
         for (u32 j = 0; j < n; j++) {
             const u32 c = p[o];
             const u32 v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
             if (v == 4) { nm |= 0x80000000u >> j; bad += c != 'N'; }
             else code |= (u64)v << (62 - 2 * j);
-            if (++o == RL) { o = 0; r++; if (r < n_rd) p = rd + seq_at[r]; }
+            if (++o == RL) { o = 0; r++; if (r < n_rd) p = rd + (rec_stride ? r * rec_stride + 8 : seq_at[r]); }
         }
     }
     rpk[w] = code; rbad[w] = nm;
     if (bad) atomicAdd(&ctr->bad_read_bytes, (unsigned long long)bad);
 }
 
+__global__ __launch_bounds__(CT) void k_frag_codes(const u8 *__restrict__ rd, u64 n, u32 rec_stride, u64 *__restrict__ codes)
+{
+    const u64 r = (u64)blockIdx.x * CT + threadIdx.x;
+    if (r >= n) return;
+    const u8 *p = rd + r * rec_stride;
+    u64 v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v |= (u64)p[i] << (8 * i);
+    codes[r] = v;
+}
+
 // ------------------------------------------------------------------ reference windows
-__global__ __launch_bounds__(CT) void k_win_count(u64 G, u32 R, const u32 *__restrict__ bad, u32 *__restrict__ blk, u32 *__restrict__ wvalid)
+struct FragFilter { u32 len; u32 mask[8]; };   // len 0: every window; else bit (c0 * 4 + c1 [* 4 + c2) * 4 + c3]) of the 2-bit codes of a listed signal
+
+__device__ __forceinline__ u32 base_code(const u64 *__restrict__ pk, u64 b) { return (u32)(pk[b >> 5] >> (62 - 2 * (b & 31))) & 3u; }
+
+__global__ __launch_bounds__(CT) void k_win_count(u64 G, u32 R, const u32 *__restrict__ bad, const u64 *__restrict__ pk, FragFilter ff,
+                                                  u32 *__restrict__ blk, u32 *__restrict__ wvalid)
 {
     __shared__ u32 wsum[4];
     const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
@@ -270,6 +289,12 @@ __global__ __launch_bounds__(CT) void k_win_count(u64 G, u32 R, const u32 *__res
         const u32 mask = (n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1u) << (32 - o - n));
         if (bad[p >> 5] & mask) ok = false;
         p += n; left -= n;
+    }
+    if (ok && ff.len) {                                     // fragmented mode: only windows whose signal this run lists (CL:712-835)
+        u32 v;
+        if (ff.len == 2) v = base_code(pk, g) * 4 + base_code(pk, g + R - 1);
+        else v = ((base_code(pk, g) * 4 + base_code(pk, g + 1)) * 4 + base_code(pk, g + R - 2)) * 4 + base_code(pk, g + R - 1);
+        ok = (ff.mask[v >> 5] >> (v & 31)) & 1u;
     }
     const u64 bal = __ballot(ok);
     const int lane = threadIdx.x & 63;
@@ -422,7 +447,7 @@ __device__ __forceinline__ u64 id_value(const Src &s, const u32 *__restrict__ id
 {
     const u64 idx = (u64)id[q] - s.G;                                   // always a read-mer of the input
     const u32 sw = (u32)(s.rsw[idx >> 6] >> (idx & 63)) & 1u;
-    return 2 * idx + (in_ref ? (sw != ref_dir) : sw);
+    return (s.codes ? s.codes[idx] : 2 * idx) + (in_ref ? (sw != ref_dir) : sw);     // CL:491-506 on the number fastqSplit wrote
 }
 
 __device__ __forceinline__ u32 lrn_len(u64 number, u32 D)
@@ -645,6 +670,8 @@ struct cora_hip_collapse {
     u64 n_r = 0, n_p = 0, n_l = 0;
     SortScratch sort_scratch;
     DevPool pool;                             // device memory of a run, kept for the next run of this object
+    FragFilter frag = {};                     // fragmented mode (cora_hip_collapse_set_fragment): the input is one fragment file
+    bool fragmented = false;
     cora_hip_collapse_stats st;
     ~cora_hip_collapse()
     {
@@ -680,14 +707,26 @@ int run_impl(cora_hip_collapse *c)
     HIPQ(hipMemsetAsync(rd.p + c->h_rd.size(), 0, 1024, s));
     if (!c->h_rd.empty()) HIPQ(hipMemcpyAsync(rd.p, c->h_rd.data(), c->h_rd.size(), hipMemcpyHostToDevice, s));
     HIPQ(hipEventRecord(ev[0], s));
-    DBuf<u64> seq_at, rpk, rsw;
+    DBuf<u64> seq_at, rpk, rsw, codes;
     DBuf<u32> rbad;
-    u64 n_rd = 0;                                           // sequence lines
-    RCQ(locate_sequence_lines(s, rd.p, c->h_rd, c->files, prm.paired != 0, tot.p, seq_at, n_rd));
-    const u64 n_items = n_rd * splits;
-    const u64 rpk_words = (n_items * R + 31) / 32 + 12;
-    RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8));
-    hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, rd.p, seq_at.p, n_rd, R * splits, rpk.p, rbad.p, rpk_words, ctr.p);
+    u64 n_rd = 0, n_items = 0;                              // sequence lines, read-mers
+    u64 rpk_words = 0;
+    if (!c->fragmented) {
+        RCQ(locate_sequence_lines(s, rd.p, c->h_rd, c->files, prm.paired != 0, tot.p, seq_at, n_rd));
+        n_items = n_rd * splits;
+        rpk_words = (n_items * R + 31) / 32 + 12;
+        RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8));
+        hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, rd.p, seq_at.p, n_rd, R * splits, 0u, rpk.p, rbad.p, rpk_words, ctr.p);
+    } else {                                                // CL:2173-2284: whole records of 8 + R bytes (fread counts items)
+        if (c->files.size() != 1) return fail(19, "the fragmented mode reads one fragment file (argv[1]); %zu were added", c->files.size());
+        const u32 rec = R + 8;
+        n_items = n_rd = c->files[0].bytes / rec;
+        rpk_words = (n_items * R + 31) / 32 + 12;
+        RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8)); RCQ(codes.alloc(n_items + 1));
+        hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, rd.p + c->files[0].off, (const u64 *)nullptr, n_rd, R, rec, rpk.p,
+                           rbad.p, rpk_words, ctr.p);
+        if (n_items) hipLaunchKernelGGL(k_frag_codes, dim3(grid_of(n_items, CT)), dim3(CT), 0, s, rd.p + c->files[0].off, n_items, rec, codes.p);
+    }
 
     // ---- the reference: packed by the table builder's kernel ----
     u64 G = 0, NW = 0, other_letters = 0;
@@ -707,21 +746,21 @@ int run_impl(cora_hip_collapse *c)
         G = dp.G;
         const u32 wb = grid_of(G, CT);
         RCQ(wvalid.alloc((u64)wb * CT / 32 + 4)); RCQ(wblk.alloc(wb)); RCQ(woff.alloc(wb));
-        hipLaunchKernelGGL(k_win_count, dim3(wb), dim3(CT), 0, s, G, R, rj->bad.p, wblk.p, wvalid.p);
+        hipLaunchKernelGGL(k_win_count, dim3(wb), dim3(CT), 0, s, G, R, rj->bad.p, rj->pk.p, c->frag, wblk.p, wvalid.p);
         RCQ(scan_u32(s, wblk.p, woff.p, wb, tot.p));
         HIPQ(hipMemcpyAsync(&NW, tot.p, 8, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
     }
     if (G + n_items >= 0xFFFFFFFFull) return fail(19, "reference positions + read-mers = %llu: 32-bit record ids do not hold that", (unsigned long long)(G + n_items));
     { u64 lim = 1; for (int i = 0; i < prm.digit_len; i++) lim *= 94;
-      if (n_items && 2 * n_items - 1 >= lim) return fail(19, "digit length %d cannot number %llu read-mers", prm.digit_len, (unsigned long long)n_items); }
+      if (!c->fragmented && n_items && 2 * n_items - 1 >= lim) return fail(19, "digit length %d cannot number %llu read-mers", prm.digit_len, (unsigned long long)n_items); }
     const u64 N = NW + n_items;
     st.ref_windows = NW; st.read_mers = n_items; st.reads = n_rd;
     HIPQ(hipEventRecord(ev[1], s));
 
     // ---- records ----
     Src src;
-    src.pk = rj ? rj->pk.p : nullptr; src.pk_words = rj ? rj->pk.n : 0; src.rpk = rpk.p; src.rbad = rbad.p; src.rpk_words = rpk_words; src.rsw = rsw.p;
+    src.pk = rj ? rj->pk.p : nullptr; src.pk_words = rj ? rj->pk.n : 0; src.rpk = rpk.p; src.rbad = rbad.p; src.rpk_words = rpk_words; src.rsw = rsw.p; src.codes = c->fragmented ? codes.p : nullptr;
     src.G = G; src.R = R; src.splits = splits;
     DBuf<u64> key, tkey;
     DBuf<u32> id, tid;
@@ -897,6 +936,37 @@ int cora_hip_collapse_set_reference(cora_hip_collapse *c, const cora_hip_fasta *
     RCQ(cora_hip_job_create(&jp, &c->ref_job));
     const int rc = cora_hip_job_set_reference_fasta(c->ref_job, fa);
     if (rc) { cora_hip_job_destroy(c->ref_job); c->ref_job = nullptr; return rc; }
+    return 0;
+}
+
+// CL:414-462: an optional "N_" in front (the flag it sets is never read), then signals of `signal_len` characters, each followed
+// by one separator character.  Reference windows are N-free, so only signals over A C G T can ever match one (CL:464-488).
+int cora_hip_collapse_set_fragment(cora_hip_collapse *c, const char *signals, int32_t signal_len)
+{
+    if (!c || !signals) return fail(10, "null argument");
+    if (signal_len != 2 && signal_len != 4) return fail(6, "fragSignalLen can only be 2 or 4");            // CL:557-561
+    if ((int)c->R < signal_len) return fail(19, "read-mers of %u bases are shorter than the signal", c->R);
+    const char *t = signals;
+    size_t n = strlen(t);
+    if (t[0] == 'N') { const size_t skip = n >= 2 ? 2 : n; t += skip; n -= skip; }
+    const size_t step = (size_t)signal_len + 1;
+    if (n % step) return fail(19, "fragmentation signals: not a whole number of signals (the reference asserts, CL:428, 452)");
+    if (n / step > 1000) return fail(19, "more than 1000 fragmentation signals (CL:410)");
+    FragFilter ff;
+    memset(&ff, 0, sizeof ff);
+    ff.len = (u32)signal_len;
+    for (size_t i = 0; i < n / step; i++) {
+        u32 v = 0;
+        bool acgt = true;
+        for (int q = 0; q < signal_len; q++) {
+            const char ch = t[i * step + q];
+            const int code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+            if (code < 0) acgt = false; else v = v * 4 + (u32)code;
+        }
+        if (acgt) ff.mask[v >> 5] |= 1u << (v & 31);
+    }
+    c->frag = ff;
+    c->fragmented = true;
     return 0;
 }
 

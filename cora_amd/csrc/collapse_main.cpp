@@ -1,11 +1,11 @@
 // collapse_main.cpp -- drop-in `collapse` / `collapse_L` (-DCHR_SHORT) executable.
 //
 // Same sixteen arguments, output files and argument errors as the reference program
-// (/root/reference/collapse.cpp:508-533, CL below; called by cora.cpp:1677-1691), for its whole-input run mode
-// (argv[13] = NONE).  The collapsing itself runs on the MI355X through libcora_hip.so (cora_hip_collapse_*); this file
-// parses the arguments and the file list, maps the inputs and writes the three results.  No CPU path.
-// Differences by design: the fragmented mode (argv[13] != NONE: binary input written by fastqSplit) is refused with
-// status 19; the process ends with status 0 instead of sending itself SIGINT (CL:2425-2427: a shortcut around slow
+// (/root/reference/collapse.cpp:508-533, CL below; called by cora.cpp:1677-1691 and 1733-1760), for its whole-input run
+// mode (argv[13] = NONE) and its fragmented mode (argv[13] = one group's signals, argv[1] = that group's fragment file).
+// The collapsing itself runs on the MI355X through libcora_hip.so (cora_hip_collapse_*); this file parses the arguments
+// and the file list, maps the inputs and writes the three results.  No CPU path.
+// Differences by design: the process ends with status 0 instead of sending itself SIGINT (CL:2425-2427: a shortcut around slow
 // deallocation; cora ignores the status, cora.cpp:1691) -- the kill-signal file (argv[15]) is still written;
 // the reference's .fai and line length (argv[5]) are not needed: the FASTA is scanned on the GPU.
 #include "../../include/cora_hip.h"
@@ -59,7 +59,7 @@ int main(int argc, char **argv)
                      "  4 reference FASTA | NOREF    5 reference line length       6 read length\n"
                      "  7 perfect matches (out)      8 unused                      9 long read names (out)\n"
                      " 10 SINGLE|PAIRED             11 FULL|HALF|THREEWAY         12 BWA|BWA_MEM|BOWTIE_2|other\n"
-                     " 13 NONE (fragment signals are not supported by this build)  14 fragment signal length\n"
+                     " 13 NONE | the signals of one fragment group (1 is then its fragment file)  14 fragment signal length\n"
                      " 15 kill signal file (out)    16 first long-read-name number - 1\n";
         return 10;                                                                                  // CL:512-533
     }
@@ -67,12 +67,9 @@ int main(int argc, char **argv)
     memset(&prm, 0, sizeof prm);
     prm.lrn_offset = (uint64_t)atoi(argv[16]);
     const std::string frag = argv[13];
-    if (frag != "NONE") {
-        const int fl = atoi(argv[14]);
-        if (fl != 2 && fl != 4) { std::cout << "fragSignalLen can only be 2 or 4" << std::endl; return 19; }    // CL:557-561
-        std::cout << "ERROR: this build runs the whole-input mode only (argv[13] = NONE, cora.cpp:1674-1692)" << std::endl;
-        return 19;
-    }
+    const bool fragmented = frag != "NONE";
+    const int frag_len = fragmented ? atoi(argv[14]) : 0;
+    if (fragmented && frag_len != 2 && frag_len != 4) { std::cout << "fragSignalLen can only be 2 or 4" << std::endl; return 6; }    // CL:557-561
     prm.read_len = atoi(argv[6]);
     const std::string split = argv[11];
     if (split == "FULL") prm.splits = 1; else if (split == "HALF") prm.splits = 2; else if (split == "THREEWAY") prm.splits = 3;
@@ -92,6 +89,10 @@ int main(int argc, char **argv)
     rc = cora_hip_collapse_create(&prm, &col);
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
 
+    if (fragmented) {
+        rc = cora_hip_collapse_set_fragment(col, argv[13], frag_len);
+        if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
+    }
     const std::string ref = argv[4];
     if (ref != "NOREF") {
         Mapped m;
@@ -103,6 +104,13 @@ int main(int argc, char **argv)
         if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
     }
 
+    if (fragmented) {                                                                              // CL:2173-2184: argv[1] is the fragment file itself
+        Mapped a;
+        if (!map_file(argv[1], a)) { std::cout << "Binary input file: " << argv[1] << " doesn't exist" << std::endl; return 5; }
+        rc = cora_hip_collapse_add_reads(col, a.p, a.n);
+        if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
+        if (a.n) munmap((void *)a.p, a.n);
+    } else
     // the list: number of samples, then per sample the reads file [the mates file] and a read count (CL:861-912)
     {
         std::ifstream list(argv[1]);

@@ -274,6 +274,11 @@ int cora_hip_collapse_set_reference(cora_hip_collapse *c, const cora_hip_fasta *
  * if paired, the mates file.  Records are four lines; the sequence line must hold at least read_len bytes of A C G T N
  * (status 78 otherwise: the reference would cut its keys at the first other byte). */
 int cora_hip_collapse_add_reads(cora_hip_collapse *c, const uint8_t *fastq, size_t bytes);
+/* The fragmented run mode (argv[13] != NONE, CL:542-563, 712-835, 2173-2284; one call per group, cora.cpp:1733-1760):
+ * signals = argv[13] (the group's line of the signals file), signal_len = argv[14].  The ONE input added with
+ * cora_hip_collapse_add_reads is then that group's fragment file as fastqSplit writes it (records of 8 bytes + a read-mer),
+ * only reference windows whose signal the group lists enter the table, and ids are built on the numbers in the records. */
+int cora_hip_collapse_set_fragment(cora_hip_collapse *c, const char *signals, int32_t signal_len);
 int cora_hip_collapse_run(cora_hip_collapse *c);
 /* The three files' bytes (argv[3], argv[7], argv[9]); valid until the next run or destroy. */
 int cora_hip_collapse_outputs(const cora_hip_collapse *c, const uint8_t **reads, size_t *reads_bytes, const uint8_t **perfect,

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import helpers
-from test_collapse_oracle import MANIFEST, build_collapse_oracle, check_outputs, check_seeded, mcg, mcs
+from test_collapse_oracle import MANIFEST, build_collapse_oracle, check_frag, check_outputs, check_seeded, mcf, mcg, mcs
 from cora_amd import collapse as ccol, hip
 
 pytestmark = pytest.mark.gpu
@@ -77,6 +77,47 @@ def test_executable_argument_errors(tmp_path):
     bad = list(args); bad[10] = "QUARTER"                                      # split mode (CL:584-588)
     r = subprocess.run([COLLAPSE_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0
-    bad = list(args); bad[12] = "FRAGMENT"                                     # fragmented mode is refused, not mis-run
+    bad = list(args); bad[12] = "AAAA_TTTT_"; bad[13] = "3"                    # signal length other than 2 or 4 (CL:557-561)
     r = subprocess.run([COLLAPSE_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 19
+    assert r.returncode == 6
+
+
+FQSPLIT_EXE = os.path.join(helpers.ROOT, "cora_amd", "bin", "fastqSplit")
+
+
+@pytest.mark.parametrize("name", sorted(mcf.CASES))
+def test_fragmented_chain_matches_the_reference(name, tmp_path):
+    """fastqSplit -> collapse once per group (argv[13] = the group's signals, long-read-name numbers carried along), both
+    drop-in executables on the GPU: the per-group files of the real reference's chain."""
+    exe = os.path.join(helpers.ROOT, "cora_amd", "bin", "collapse_L" if mcf.CASES[name][4] else "collapse")
+    outs, codes = mcf.run(FQSPLIT_EXE, exe, name, str(tmp_path))
+    assert set(codes) == {0}, codes
+    check_frag(name, outs)
+
+
+def test_fragmented_mode_through_the_cabi(tmp_path):
+    from cora_amd import fastqsplit
+    name = "f_paired_sig2_g10_bwamem"
+    fcase, ref, D, mapper, Lvar = mcf.CASES[name]
+    sets, mode, n, size = mcf.mfg.CASES[fcase]
+    L = mcg.READ_SETS[sets[0]][1]
+    sig = mcf.mfg.frag_text(n, size)
+    fs = fastqsplit.FastqSplit(sig.encode(), L, mode)
+    for s in sets:
+        fs.add_reads(open(os.path.join(mcg.INP, s + "_1.fq"), "rb").read())
+        fs.add_reads(open(os.path.join(mcg.INP, s + "_2.fq"), "rb").read())
+    fs.run()
+    tokens = sig.split("\n")[1:1 + n]
+    outs, lrn = [], 0
+    for g in range(n):
+        c = ccol.Collapse(D, L, mcf.MODES[mode][0], mcf.MODES[mode][1], mapper, Lvar, lrn)
+        c.set_fragment(tokens[g], size)
+        c.set_reference(open(os.path.join(helpers.GOLDEN, "inputs", ref + ".fa"), "rb").read())
+        c.add_reads(fs.group(g))
+        c.run()
+        o = c.outputs()
+        c.close()
+        outs.append(o)
+        lrn += o[2].count(b"\n")
+    fs.close()
+    check_frag(name, outs)
