@@ -43,6 +43,17 @@ class Collapse:
         f.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
         hip._check(f(self._h, signals.encode(), signal_len))
 
+    def set_lrn_offset(self, lrn_offset: int):
+        f = hip.lib().cora_hip_collapse_set_lrn_offset
+        f.argtypes = [C.c_void_p, C.c_uint64]
+        hip._check(f(self._h, lrn_offset))
+
+    def add_reads_device(self, dev_ptr: int, nbytes: int):
+        """Fragmented mode: a fragment already in HBM (FastqSplit.group_device); borrowed until run() returns."""
+        f = hip.lib().cora_hip_collapse_add_reads_device
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        hip._check(f(self._h, C.c_void_p(dev_ptr), nbytes))
+
     def add_reads(self, fastq_image: bytes):
         buf = (C.c_char * max(1, len(fastq_image))).from_buffer_copy(fastq_image or b"\0")
         hip._check(hip.lib().cora_hip_collapse_add_reads(self._h, C.cast(buf, C.c_void_p), len(fastq_image)))

@@ -92,14 +92,17 @@ struct cora_hip_fqsplit {
     std::vector<u8> h_rd;
     std::vector<ReadFile> files;
     HBuf<u8> out;
+    DBuf<u8> d_out;                           // the fragment files, one behind the other, kept in HBM until the next run
     u64 group_start[257] = {};                // in records
     u32 RS = 0;
+    bool device_only = false;                 // leave the fragment files in HBM (cora_hip_fqsplit_group_device), no copy to the host
     SortScratch sort_scratch;
     DevPool pool;
     cora_hip_fqsplit_stats st;
     ~cora_hip_fqsplit()
     {
         sort_scratch.release();
+        d_out.release();
         pool.destroy();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -164,12 +167,14 @@ int fs_run(cora_hip_fqsplit *c)
     HIPQ(hipEventRecord(ev[3], s));
 
     const u64 total = n_items * RS;
-    DBuf<u8> d_out;
+    DBuf<u8> &d_out = c->d_out;
     RCQ(d_out.alloc(total + 32));
     if (total) hipLaunchKernelGGL(k_fs_write, dim3(grid_of((total + 15) / 16, CT)), dim3(CT), 0, s, rd.p, seq_at.p, order, n_items, fp, d_out.p);
     HIPQ(hipEventRecord(ev[4], s));
-    RCQ(c->out.reserve(total + 1));
-    if (total) HIPQ(hipMemcpyAsync(c->out.p, d_out.p, total, hipMemcpyDeviceToHost, s));
+    if (!c->device_only) {
+        RCQ(c->out.reserve(total + 1));
+        if (total) HIPQ(hipMemcpyAsync(c->out.p, d_out.p, total, hipMemcpyDeviceToHost, s));
+    }
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
     cora_hip_fqsplit_stats &st = c->st;
@@ -263,6 +268,13 @@ int cora_hip_fqsplit_add_reads(cora_hip_fqsplit *c, const uint8_t *fastq, size_t
     return 0;
 }
 
+int cora_hip_fqsplit_set_device_only(cora_hip_fqsplit *c, int32_t on)
+{
+    if (!c) return fail(10, "null argument");
+    c->device_only = on != 0;
+    return 0;
+}
+
 int cora_hip_fqsplit_run(cora_hip_fqsplit *c)
 {
     if (!c) return fail(10, "null argument");
@@ -274,7 +286,17 @@ int cora_hip_fqsplit_group(const cora_hip_fqsplit *c, int32_t group, const uint8
 {
     if (!c || !bytes || !n) return fail(10, "null argument");
     if (group < 0 || group >= c->prm.n_groups) return fail(19, "group %d outside 0..%d", group, c->prm.n_groups - 1);
+    if (c->device_only) return fail(19, "the fragment files were left in HBM (cora_hip_fqsplit_set_device_only): ask for cora_hip_fqsplit_group_device");
     *bytes = c->out.p ? c->out.p + c->group_start[group] * c->RS : nullptr;
+    *n = (size_t)((c->group_start[group + 1] - c->group_start[group]) * c->RS);
+    return 0;
+}
+
+int cora_hip_fqsplit_group_device(const cora_hip_fqsplit *c, int32_t group, const void **dev, size_t *n)
+{
+    if (!c || !dev || !n) return fail(10, "null argument");
+    if (group < 0 || group >= c->prm.n_groups) return fail(19, "group %d outside 0..%d", group, c->prm.n_groups - 1);
+    *dev = c->d_out.p ? c->d_out.p + c->group_start[group] * c->RS : nullptr;
     *n = (size_t)((c->group_start[group + 1] - c->group_start[group]) * c->RS);
     return 0;
 }

@@ -32,6 +32,7 @@ def _bind(lib):
     lib.cora_hip_fqsplit_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.cora_hip_fqsplit_run.argtypes = [C.c_void_p]
     lib.cora_hip_fqsplit_group.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.cora_hip_fqsplit_group_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.cora_hip_fqsplit_get_stats.argtypes = [C.c_void_p, C.POINTER(FqSplitStats)]
     lib.cora_hip_fqsplit_destroy.argtypes = [C.c_void_p]
     lib.cora_hip_fqsplit_destroy.restype = None
@@ -62,6 +63,11 @@ class FastqSplit:
         buf = (C.c_char * max(1, len(fastq_image))).from_buffer_copy(fastq_image or b"\0")
         hip._check(self._lib.cora_hip_fqsplit_add_reads(self._h, C.cast(buf, C.c_void_p), len(fastq_image)))
 
+    def set_device_only(self, on: bool = True):
+        f = self._lib.cora_hip_fqsplit_set_device_only
+        f.argtypes = [C.c_void_p, C.c_int32]
+        hip._check(f(self._h, int(on)))
+
     def run(self):
         hip._check(self._lib.cora_hip_fqsplit_run(self._h))
 
@@ -69,6 +75,12 @@ class FastqSplit:
         ptr, n = C.c_void_p(), C.c_size_t()
         hip._check(self._lib.cora_hip_fqsplit_group(self._h, g, C.byref(ptr), C.byref(n)))
         return C.string_at(ptr, n.value) if n.value else b""
+
+    def group_device(self, g: int):
+        """(device pointer, bytes) of the group's fragment file where the run left it in HBM."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        hip._check(self._lib.cora_hip_fqsplit_group_device(self._h, g, C.byref(ptr), C.byref(n)))
+        return (ptr.value or 0), n.value
 
     def groups(self):
         return [self.group(g) for g in range(self.n_groups)]

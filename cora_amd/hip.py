@@ -28,10 +28,10 @@ EXPORTS = [
     "cora_hip_tables_export", "cora_hip_tables_lookup_equiv", "cora_hip_tables_destroy",
     "cora_hip_fasta_scan", "cora_hip_fasta_get_info", "cora_hip_fasta_fai_text", "cora_hip_fasta_contig",
     "cora_hip_fasta_destroy", "cora_hip_job_set_reference_fasta",
-    "cora_hip_collapse_table_geometry", "cora_hip_collapse_create", "cora_hip_collapse_set_reference", "cora_hip_collapse_set_fragment", "cora_hip_collapse_add_reads",
+    "cora_hip_collapse_table_geometry", "cora_hip_collapse_create", "cora_hip_collapse_set_reference", "cora_hip_collapse_set_fragment", "cora_hip_collapse_set_lrn_offset", "cora_hip_collapse_add_reads", "cora_hip_collapse_add_reads_device",
     "cora_hip_collapse_run", "cora_hip_collapse_outputs", "cora_hip_collapse_get_stats", "cora_hip_collapse_destroy",
     "cora_hip_fqsplit_parse_signals", "cora_hip_fqsplit_create", "cora_hip_fqsplit_add_reads", "cora_hip_fqsplit_run",
-    "cora_hip_fqsplit_group", "cora_hip_fqsplit_get_stats", "cora_hip_fqsplit_destroy",
+    "cora_hip_fqsplit_group", "cora_hip_fqsplit_group_device", "cora_hip_fqsplit_set_device_only", "cora_hip_fqsplit_get_stats", "cora_hip_fqsplit_destroy",
 ]
 
 

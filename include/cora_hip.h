@@ -279,6 +279,14 @@ int cora_hip_collapse_add_reads(cora_hip_collapse *c, const uint8_t *fastq, size
  * cora_hip_collapse_add_reads is then that group's fragment file as fastqSplit writes it (records of 8 bytes + a read-mer),
  * only reference windows whose signal the group lists enter the table, and ids are built on the numbers in the records. */
 int cora_hip_collapse_set_fragment(cora_hip_collapse *c, const char *signals, int32_t signal_len);
+/* One object can take group after group (cora.cpp:1733-1760 starts a process per group): cora_hip_collapse_set_fragment
+ * drops the previous input and keeps the reference; this sets argv[16] for the next run (long read names are numbered on). */
+int cora_hip_collapse_set_lrn_offset(cora_hip_collapse *c, uint64_t lrn_offset);
+/* Fragmented mode only, in place of cora_hip_collapse_add_reads: the fragment is already in this GPU's memory (as
+ * cora_hip_fqsplit_group_device hands it out) and is read where it lies: the fastqSplit -> collapse chain without the
+ * fragments crossing PCIe.  No counterpart in the reference, whose two programs meet in files.  The memory is borrowed: it
+ * must stay valid and unchanged until cora_hip_collapse_run has returned. */
+int cora_hip_collapse_add_reads_device(cora_hip_collapse *c, const void *fragment_dev, size_t bytes);
 int cora_hip_collapse_run(cora_hip_collapse *c);
 /* The three files' bytes (argv[3], argv[7], argv[9]); valid until the next run or destroy. */
 int cora_hip_collapse_outputs(const cora_hip_collapse *c, const uint8_t **reads, size_t *reads_bytes, const uint8_t **perfect,
@@ -320,6 +328,10 @@ int cora_hip_fqsplit_add_reads(cora_hip_fqsplit *s, const uint8_t *fastq, size_t
 int cora_hip_fqsplit_run(cora_hip_fqsplit *s);
 /* Bytes of <prefix>.frag<group>; valid until the next run or destroy. */
 int cora_hip_fqsplit_group(const cora_hip_fqsplit *s, int32_t group, const uint8_t **bytes, size_t *n);
+/* on != 0: runs leave the fragment files in HBM only (no copy to the host; cora_hip_fqsplit_group then fails with 19). */
+int cora_hip_fqsplit_set_device_only(cora_hip_fqsplit *s, int32_t on);
+/* The same bytes where the run left them in HBM (device pointer; valid until the next run or destroy). */
+int cora_hip_fqsplit_group_device(const cora_hip_fqsplit *s, int32_t group, const void **dev, size_t *n);
 int cora_hip_fqsplit_get_stats(const cora_hip_fqsplit *s, cora_hip_fqsplit_stats *out);
 void cora_hip_fqsplit_destroy(cora_hip_fqsplit *s);
 

@@ -95,9 +95,11 @@ def test_fragmented_chain_matches_the_reference(name, tmp_path):
     check_frag(name, outs)
 
 
-def test_fragmented_mode_through_the_cabi(tmp_path):
+@pytest.mark.parametrize("in_hbm", [False, True])
+@pytest.mark.parametrize("name", ["f_paired_sig2_g10_bwamem", "f_threeway_paired_g8_L", "f_split_paired_g2_noref"])
+def test_fragmented_mode_through_the_cabi(name, in_hbm):
+    """in_hbm: the fragments go from fastqSplit to collapse as device memory (cora_hip_collapse_add_reads_device)."""
     from cora_amd import fastqsplit
-    name = "f_paired_sig2_g10_bwamem"
     fcase, ref, D, mapper, Lvar = mcf.CASES[name]
     sets, mode, n, size = mcf.mfg.CASES[fcase]
     L = mcg.READ_SETS[sets[0]][1]
@@ -112,12 +114,48 @@ def test_fragmented_mode_through_the_cabi(tmp_path):
     for g in range(n):
         c = ccol.Collapse(D, L, mcf.MODES[mode][0], mcf.MODES[mode][1], mapper, Lvar, lrn)
         c.set_fragment(tokens[g], size)
-        c.set_reference(open(os.path.join(helpers.GOLDEN, "inputs", ref + ".fa"), "rb").read())
-        c.add_reads(fs.group(g))
+        if ref:
+            c.set_reference(open(os.path.join(helpers.GOLDEN, "inputs", ref + ".fa"), "rb").read())
+        if in_hbm:
+            c.add_reads_device(*fs.group_device(g))
+        else:
+            c.add_reads(fs.group(g))
         c.run()
         o = c.outputs()
         c.close()
         outs.append(o)
         lrn += o[2].count(b"\n")
+    fs.close()
+    check_frag(name, outs)
+
+
+def test_one_object_takes_group_after_group():
+    """The chain with ONE collapse object (reference scanned and packed once) and the fragments left in HBM."""
+    from cora_amd import fastqsplit
+    name = "f_paired_g4_bt2"
+    fcase, ref, D, mapper, Lvar = mcf.CASES[name]
+    sets, mode, n, size = mcf.mfg.CASES[fcase]
+    L = mcg.READ_SETS[sets[0]][1]
+    sig = mcf.mfg.frag_text(n, size)
+    fs = fastqsplit.FastqSplit(sig.encode(), L, mode)
+    for s in sets:
+        fs.add_reads(open(os.path.join(mcg.INP, s + "_1.fq"), "rb").read())
+        fs.add_reads(open(os.path.join(mcg.INP, s + "_2.fq"), "rb").read())
+    fs.set_device_only(True)
+    fs.run()
+    with pytest.raises(hip.CoraHipError):
+        fs.group(0)
+    tokens = sig.split("\n")[1:1 + n]
+    c = ccol.Collapse(D, L, mcf.MODES[mode][0], mcf.MODES[mode][1], mapper, Lvar, 0)
+    c.set_reference(open(os.path.join(helpers.GOLDEN, "inputs", ref + ".fa"), "rb").read())
+    outs, lrn = [], 0
+    for g in range(n):
+        c.set_fragment(tokens[g], size)
+        c.set_lrn_offset(lrn)
+        c.add_reads_device(*fs.group_device(g))
+        c.run()
+        outs.append(c.outputs())
+        lrn += outs[-1][2].count(b"\n")
+    c.close()
     fs.close()
     check_frag(name, outs)
