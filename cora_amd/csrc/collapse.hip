@@ -248,12 +248,22 @@ __global__ __launch_bounds__(CT) void k_reads_pack(const u8 *__restrict__ rd, co
         u32 o = (u32)(b0 - r * RL);
         const u8 *p = rd + (rec_stride ? r * rec_stride + 8 : seq_at[r]);
         const u32 n = (u32)min((u64)32, total - b0);
-        for (u32 j = 0; j < n; j++) {
-            const u32 c = p[o];
-            const u32 v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
-            if (v == 4) { nm |= 0x80000000u >> j; bad += c != 'N'; }
-            else code |= (u64)v << (62 - 2 * j);
-            if (++o == RL) { o = 0; r++; if (r < n_rd) p = rd + (rec_stride ? r * rec_stride + 8 : seq_at[r]); }
+        u32 j = 0;
+        while (j < n) {                                      // one stretch per read the 32 bases touch
+            const u32 len = min(n - j, RL - o);
+            ByteRun run(p + o, len);
+            while (run.more()) {
+                u32 cnt;
+                u32 four = run.next(cnt);
+                for (u32 t = 0; t < cnt; t++, j++, four >>= 8) {
+                    const u32 c = four & 0xFFu;
+                    const u32 v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+                    if (v == 4) { nm |= 0x80000000u >> j; bad += c != 'N'; }
+                    else code |= (u64)v << (62 - 2 * j);
+                }
+            }
+            o += len;
+            if (o == RL) { o = 0; r++; if (r < n_rd) p = rd + (rec_stride ? r * rec_stride + 8 : seq_at[r]); }
         }
     }
     rpk[w] = code; rbad[w] = nm;

@@ -60,28 +60,35 @@ __global__ __launch_bounds__(CT) void k_fs_write(const u8 *__restrict__ rd, cons
     if (b0 >= total) return;
     u64 j = b0 / RS;
     u32 o = (u32)(b0 - j * RS);
-    u32 w[4] = {0, 0, 0, 0};
-    u64 code = 0;
-    const u8 *body = nullptr;
-    bool loaded = false;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (b0 + i < total) {
-            if (!loaded) {
-                const u64 src = order ? (u64)order[j] : j;
-                const u64 line = src / prm.splits;
-                u32 s = (u32)(src - line * prm.splits);
-                if (prm.slip && s == 2 && !(line & 1)) s = 1;
-                code = 2 * src;
-                body = rd + seq_at[line] + (u64)s * prm.R;
-                loaded = true;
-            }
-            const u32 c = o < 8 ? (u32)(code >> (8 * o)) & 0xFFu : (u32)body[o - 8];
-            w[i >> 2] |= c << (8 * (i & 3));
-            if (++o == RS) { o = 0; j++; loaded = false; }
+    u64 wlo = 0, whi = 0;                                    // the 16 bytes (no run-time register indexing)
+    const u32 n = (u32)min((u64)16, total - b0);
+    u32 i = 0;
+    while (i < n) {                                          // at most two records meet in 16 bytes (a record is 10 bytes or more)
+        const u64 src = order ? (u64)order[j] : j;
+        const u64 line = src / prm.splits;
+        u32 s = (u32)(src - line * prm.splits);
+        if (prm.slip && s == 2 && !(line & 1)) s = 1;
+        const u64 code = 2 * src;
+        for (; o < 8 && i < n; o++, i++) {
+            const u64 c = (code >> (8 * o)) & 0xFFull;
+            if (i < 8) wlo |= c << (8 * i); else whi |= c << (8 * (i - 8));
         }
+        if (i < n) {
+            const u32 len = min(n - i, RS - o);
+            ByteRun run(rd + seq_at[line] + (u64)s * prm.R + (o - 8), len);
+            while (run.more()) {
+                u32 cnt;
+                u32 four = run.next(cnt);
+                for (u32 q = 0; q < cnt; q++, i++, four >>= 8) {
+                    const u64 c = four & 0xFFu;
+                    if (i < 8) wlo |= c << (8 * i); else whi |= c << (8 * (i - 8));
+                }
+            }
+            o += len;
+        }
+        if (o == RS) { o = 0; j++; }
     }
-    *reinterpret_cast<uint4 *>(out + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4 *>(out + b0) = make_uint4((u32)wlo, (u32)(wlo >> 32), (u32)whi, (u32)(whi >> 32));
 }
 
 }  // namespace
