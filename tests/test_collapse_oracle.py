@@ -94,8 +94,10 @@ def test_oracle_refuses_what_it_does_not_restate(tmp_path):
     args = [build_collapse_oracle(), str(lst), "3", str(tmp_path / "r"), "NOREF", "60", "100", str(tmp_path / "p"), "0", str(tmp_path / "l"),
             "SINGLE", "FULL", "GENERIC", "NONE", "0", str(tmp_path / "k"), "0"]
     assert subprocess.run(args, stderr=subprocess.DEVNULL).returncode == 78
-    args[13] = "AA_AC_"
-    assert subprocess.run(args, stderr=subprocess.DEVNULL).returncode == 19
+    args[13], args[14] = "AA_AC_", "3"                       # fragment signal length other than 2 or 4 (collapse.cpp:557-561)
+    assert subprocess.run(args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 6
+    args[13], args[14] = "AA_AC", "2"                        # not a whole number of signals: the reference asserts
+    assert subprocess.run(args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 19
 
 
 import make_collapse_seeded as mcs  # noqa: E402
