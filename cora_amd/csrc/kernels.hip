@@ -957,6 +957,7 @@ __global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restri
     constexpr u32 INV = 0xFFFFFFFFu;
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_active) return;
+    if (WRITE && cnt_recs[t] == 0) return;                  // the counting pass found nothing to report here: no second look at the genome
     const u64 i = active[t];
     u32 nrec = 0, ncand = 0;
     u64 at = WRITE ? rec_off[t] : 0;
@@ -1673,10 +1674,10 @@ void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const
                                      cnt_cand, (const u64 *)nullptr, (PairRec *)nullptr, sketch);
 }
 void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
-                         const u64 *rec_off, PairRec *pairs, const u32 *sketch)
+                         const u64 *rec_off, u32 *cnt_recs, PairRec *pairs, const u32 *sketch)
 {
     if (n_active) hipLaunchKernelGGL((k_verify<true>), grid_for(n_active), dim3(256), 0, s, p, pk, codes, active, n_active, seed,
-                                     (u32 *)nullptr, (u32 *)nullptr, rec_off, pairs, sketch);
+                                     cnt_recs, (u32 *)nullptr, rec_off, pairs, sketch);
 }
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta)
 {

@@ -101,7 +101,7 @@ void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u6
 void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,
                          int seed, u32 *cnt_recs, u32 *cnt_cand, const u32 *sketch /* sorted with the codes, or null */);
 void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,
-                         int seed, const u64 *rec_off, PairRec *pairs, const u32 *sketch);
+                         int seed, const u64 *rec_off, u32 *cnt_recs, PairRec *pairs, const u32 *sketch);
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta);
 void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr);
 void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start);

@@ -274,7 +274,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         std::swap(ps.pairs.p, bigger.p); std::swap(ps.pairs.n, bigger.n); std::swap(ps.pairs.pool, bigger.pool);
         ps.cap = want;
     }
-    if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, rec_off.p, ps.pairs.p + ps.n, ck.c);
+    if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, rec_off.p, cnt_recs.p, ps.pairs.p + ps.n, ck.c);
     ps.n += totals[0];
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
