@@ -24,6 +24,8 @@ CASES = {   # name: (fastqSplit case, reference or None, D, mapper, L variant)
     "f_threeway_paired_sig2_g10": ("threeway_paired_2_g10", "syn", 4, "GENERIC", False),
     "f_single_g1": ("single_4_g1", "fam", 3, "GENERIC", False),
     "f_split_paired_g2_noref": ("split_paired_4_g2_odd", None, 3, "GENERIC", False),
+    "f_big_noref_g4": ("single_4_g4_big", None, 3, "GENERIC", False),       # long-read-name numbers run on through the groups
+    "f_big_g4_bwa": ("single_4_g4_big", "syn", 3, "BWA", False),
     "f_two_samples_g8_d2": ("single_4_g8_two_samples", "syn", 2, "GENERIC", False),
 }
 

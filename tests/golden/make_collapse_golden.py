@@ -86,6 +86,7 @@ READ_SETS = {          # name: (reference, L, n, seed, paired)
     "multi60p": ("multi", 60, 500, 5, True),
     "fam75s": ("fam", 75, 800, 6, False),
     "syn100s_b": ("syn", 100, 300, 7, False),
+    "syn100s_big": ("syn", 100, 6000, 8, False),     # popular reads with hundreds of copies: long read names in most fragment groups
 }
 
 CASES = {   # name: (read sets (samples), reference or None, D, input mode, split, mapper, L variant, lrn offset, keep bytes)

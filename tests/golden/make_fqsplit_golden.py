@@ -43,6 +43,7 @@ CASES = {   # name: (read sets (samples), mapping mode, groups, signal size)
     "split_paired_4_g2_odd": (["syn101p"], "SPLIT_PAIRED", 2, 4),
     "threeway_paired_4_g8": (["multi60p"], "THREEWAY_PAIRED", 8, 4),
     "single_4_g1": (["fam75s"], "SINGLE", 1, 4),
+    "single_4_g4_big": (["syn100s_big"], "SINGLE", 4, 4),
     "single_2_g2": (["syn100s"], "SINGLE", 2, 2),
     "split_single_2_g10": (["fam75s"], "SPLIT_SINGLE", 10, 2),
     "threeway_single_2_g2": (["syn100s"], "THREEWAY_SINGLE", 2, 2),
