@@ -188,3 +188,62 @@ class ShardedJob:
         if c.rank == 0:
             self._stage(ST_COLLECT)
         torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The read side over several GPUs (fastqSplit -> collapse in its fragmented mode).
+# Fragment groups are independent: rank r takes the groups g with g % world == r, and no read-mer ever crosses a link.
+# The only thing that chains the groups is the numbering of long read names (cora.cpp:1762-1776 counts the lines of every
+# group's list before it starts the next group); which names are long does not depend on the numbers, so every rank first
+# runs its groups numbered from 0, the counts are summed over the ranks (one small all-reduce), and only the groups that
+# hold long names AND start at another number are run again.
+# ---------------------------------------------------------------------------------------------------------------
+def lrn_offsets(first, counts):
+    """counts[g] = long read names of group g  ->  the number each group's names start after (cora.cpp:1776)."""
+    out, at = [], first
+    for n in counts:
+        out.append(at)
+        at += n
+    return out
+
+
+def read_chain_sharded(comm, signals_text, read_len, mode, fastq_images, reference_image, digit_len, mapper="GENERIC",
+                       chr_short=False, lrn_offset=0):
+    """Every rank calls this with the same inputs; returns {group: [reads, perfect, lrn] bytes} for the groups this rank
+    owns.  Group g's files are the bytes the reference's chain writes as <file>.split<g>."""
+    from . import collapse as ccol
+    from . import fastqsplit
+    fs = fastqsplit.FastqSplit(signals_text, read_len, mode)
+    for img in fastq_images:
+        fs.add_reads(img)
+    fs.set_device_only(True)
+    fs.run()
+    splits, paired = fastqsplit.MODES[mode]
+    text = signals_text.decode()
+    size = int(text.split()[1])
+    lines = text.split("\n")[1:1 + fs.n_groups]
+    col = ccol.Collapse(digit_len, read_len, "PAIRED" if paired else "SINGLE", {1: "FULL", 2: "HALF", 3: "THREEWAY"}[splits], mapper,
+                        chr_short, lrn_offset)
+    if reference_image is not None:
+        col.set_reference(reference_image)
+    own = [g for g in range(fs.n_groups) if g % comm.world == comm.rank]
+
+    def run_group(g, first):
+        col.set_fragment(lines[g], size)
+        col.set_lrn_offset(first)
+        col.add_reads_device(*fs.group_device(g))
+        col.run()
+        return col.outputs(), col.stats()["lrn_names"]
+
+    outs, counts = {}, torch.zeros(fs.n_groups, dtype=torch.int64, device=comm.device)
+    for g in own:
+        outs[g], n = run_group(g, lrn_offset)
+        counts[g] = n
+    counts = [int(x) for x in comm.all_reduce_sum(counts).tolist()]
+    first = lrn_offsets(lrn_offset, counts)
+    for g in own:
+        if counts[g] and first[g] != lrn_offset:
+            outs[g], _ = run_group(g, first[g])
+    col.close()
+    fs.close()
+    return outs

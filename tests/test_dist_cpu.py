@@ -27,3 +27,11 @@ def test_sharded_job_needs_the_library():
         pytest.skip("GPU present")
     with pytest.raises(hip.CoraHipError):
         hip.init(0)
+
+
+def test_lrn_offsets_follow_the_group_order():
+    """cora.cpp:1762-1776: every group's long read names are numbered on from the groups before it."""
+    from cora_amd import dist as cdist
+    assert cdist.lrn_offsets(0, [3, 0, 2, 5]) == [0, 3, 3, 5]
+    assert cdist.lrn_offsets(7, [0, 0]) == [7, 7]
+    assert cdist.lrn_offsets(0, []) == []

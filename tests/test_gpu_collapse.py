@@ -159,3 +159,22 @@ def test_one_object_takes_group_after_group():
     c.close()
     fs.close()
     check_frag(name, outs)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_read_chain_sharded_over_ranks(world, tmp_path):
+    """Fragment groups dealt over ranks (cora_amd.dist.read_chain_sharded; gloo, all ranks on this GPU): every group's files are
+    the reference chain's, long-read-name numbers included although no rank saw the groups before its own."""
+    import sys
+    cases = ["f_big_noref_g4", "f_paired_sig2_g10_bwamem", "f_threeway_paired_g8_L"]
+    script = os.path.join(helpers.ROOT, "tests", "support", "read_chain_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29530 + world), CORA_TEST_CASES=",".join(cases), CORA_TEST_OUT=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=280)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    for name in cases:
+        n = mcf.mfg.CASES[mcf.CASES[name][0]][2]
+        got = [[open(os.path.join(str(tmp_path), "%s.%s.split%d" % (name, fn, g)), "rb").read() for fn in ("reads", "perfect", "lrn")] for g in range(n)]
+        check_frag(name, got)
