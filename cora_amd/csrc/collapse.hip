@@ -682,7 +682,8 @@ struct cora_hip_collapse {
     DevPool pool;                             // device memory of a run, kept for the next run of this object
     FragFilter frag = {};                     // fragmented mode (cora_hip_collapse_set_fragment): the input is one fragment file
     bool fragmented = false;
-    const u8 *dev_in = nullptr;               // fragmented mode: a fragment that is already in HBM (cora_hip_collapse_add_reads_device)
+    bool has_dev_in = false;                  // fragmented mode: a fragment that is already in HBM (cora_hip_collapse_add_reads_device)
+    const u8 *dev_in = nullptr;
     size_t dev_in_bytes = 0;
     cora_hip_collapse_stats st;
     ~cora_hip_collapse()
@@ -715,7 +716,7 @@ int run_impl(cora_hip_collapse *c)
 
     // ---- the reads: images to HBM, sequence line of every record ----
     DBuf<u8> rd;
-    if (!c->dev_in) {
+    if (!c->has_dev_in) {
         RCQ(rd.alloc(c->h_rd.size() + 1024));
         HIPQ(hipMemsetAsync(rd.p + c->h_rd.size(), 0, 1024, s));
         if (!c->h_rd.empty()) HIPQ(hipMemcpyAsync(rd.p, c->h_rd.data(), c->h_rd.size(), hipMemcpyHostToDevice, s));
@@ -732,10 +733,10 @@ int run_impl(cora_hip_collapse *c)
         RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8));
         hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, rd.p, seq_at.p, n_rd, R * splits, 0u, rpk.p, rbad.p, rpk_words, ctr.p);
     } else {                                                // CL:2173-2284: whole records of 8 + R bytes (fread counts items)
-        if (!c->dev_in && c->files.size() != 1) return fail(19, "the fragmented mode reads one fragment file (argv[1]); %zu were added", c->files.size());
+        if (!c->has_dev_in && c->files.size() != 1) return fail(19, "the fragmented mode reads one fragment file (argv[1]); %zu were added", c->files.size());
         const u32 rec = R + 8;
-        const u8 *frag = c->dev_in ? c->dev_in : rd.p + c->files[0].off;
-        n_items = n_rd = (c->dev_in ? c->dev_in_bytes : c->files[0].bytes) / rec;
+        const u8 *frag = c->has_dev_in ? c->dev_in : rd.p + c->files[0].off;
+        n_items = n_rd = (c->has_dev_in ? c->dev_in_bytes : c->files[0].bytes) / rec;
         rpk_words = (n_items * R + 31) / 32 + 12;
         RCQ(rpk.alloc(rpk_words)); RCQ(rbad.alloc(rpk_words)); RCQ(rsw.alloc(n_items / 64 + 8)); RCQ(codes.alloc(n_items + 1));
         hipLaunchKernelGGL(k_reads_pack, dim3(grid_of(rpk_words, CT)), dim3(CT), 0, s, frag, (const u64 *)nullptr, n_rd, R, rec, rpk.p,
@@ -983,7 +984,7 @@ int cora_hip_collapse_set_fragment(cora_hip_collapse *c, const char *signals, in
     c->frag = ff;
     c->fragmented = true;
     c->files.clear(); c->h_rd.clear();          // a new group: its own input (the reference and the device pool stay)
-    c->dev_in = nullptr; c->dev_in_bytes = 0;
+    c->has_dev_in = false; c->dev_in = nullptr; c->dev_in_bytes = 0;
     return 0;
 }
 
@@ -1011,8 +1012,8 @@ int cora_hip_collapse_add_reads_device(cora_hip_collapse *c, const void *fragmen
     if (!c || (!fragment_dev && bytes)) return fail(10, "null argument");
     if (!c->fragmented) return fail(19, "a device-resident input needs the fragmented mode (cora_hip_collapse_set_fragment first)");
     if (!c->files.empty()) return fail(19, "the fragmented mode reads one fragment file; one was already added");
-    static const u8 nothing = 0;
-    c->dev_in = bytes ? (const u8 *)fragment_dev : &nothing;
+    c->has_dev_in = true;
+    c->dev_in = (const u8 *)fragment_dev;
     c->dev_in_bytes = bytes;
     return 0;
 }
