@@ -29,46 +29,39 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *lds, u32 *total)
 }
 
 // ------------------------------------------------------------------ FASTQ: sequence line of every record
-__global__ __launch_bounds__(CT) void k_nl_count(const u8 *__restrict__ img, u64 n, u32 *__restrict__ blk)
+// First pass: every lane looks at 16 bytes and keeps which of them are line ends (16 bits); blocks count them.
+__global__ __launch_bounds__(CT) void k_nl_count(const u8 *__restrict__ img, u64 n, u32 *__restrict__ blk, unsigned short *__restrict__ nl_mask)
 {
     __shared__ u32 lds[4];
-    const u64 at = ((u64)blockIdx.x * CT + threadIdx.x) * 16;
-    u32 c = 0;
+    const u64 t = (u64)blockIdx.x * CT + threadIdx.x, at = t * 16;
+    u32 m = 0;
     if (at < n) {
         const uint4 v = *reinterpret_cast<const uint4 *>(img + at);
         const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 16; i++) c += (at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n';
+        for (int i = 0; i < 16; i++) m |= (u32)((at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n') << i;
+        nl_mask[t] = (unsigned short)m;
     }
     u32 tot;
-    block_excl_scan(c, lds, &tot);
+    block_excl_scan((u32)__popc(m), lds, &tot);
     if (threadIdx.x == 0) blk[blockIdx.x] = tot;
 }
 
-// newline number j of the file (0-based) with j % 4 == 0 ends a header line: the sequence of record j / 4 starts behind it
-// (and ends at newline j + 1: kept when seq_end is given)
-__global__ __launch_bounds__(CT) void k_fq_emit(const u8 *__restrict__ img, u64 n, const u64 *__restrict__ blk_off, u64 file_off,
+// Second pass, over the masks alone (an eighth of the image's bytes): newline number j of the file (0-based) with
+// j % 4 == 0 ends a header line: the sequence of record j / 4 starts behind it (and ends at newline j + 1: kept when seq_end is given)
+__global__ __launch_bounds__(CT) void k_fq_emit(const unsigned short *__restrict__ nl_mask, u64 n, const u64 *__restrict__ blk_off, u64 file_off,
                                                 u64 *__restrict__ seq_at, u64 *__restrict__ seq_end, u64 first_read, u32 stride, u64 n_records)
 {
     __shared__ u32 lds[4];
-    const u64 at = ((u64)blockIdx.x * CT + threadIdx.x) * 16;
-    u32 c = 0;
-    u32 w[4] = {0, 0, 0, 0};
-    if (at < n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(img + at);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-#pragma unroll
-        for (int i = 0; i < 16; i++) c += (at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n';
-    }
-    u64 j = blk_off[blockIdx.x] + block_excl_scan(c, lds, nullptr);
-    if (!c) return;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if ((at + i < n) && ((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == '\n') {
-            if ((j & 3) == 0 && (j >> 2) < n_records) seq_at[(first_read + (j >> 2)) * stride] = file_off + at + i + 1;
-            if (seq_end && (j & 3) == 1 && (j >> 2) < n_records) seq_end[(first_read + (j >> 2)) * stride] = file_off + at + i;
-            j++;
-        }
+    const u64 t = (u64)blockIdx.x * CT + threadIdx.x, at = t * 16;
+    u32 m = at < n ? (u32)nl_mask[t] : 0u;
+    u64 j = blk_off[blockIdx.x] + block_excl_scan((u32)__popc(m), lds, nullptr);
+    while (m) {
+        const u32 i = (u32)__ffs((int)m) - 1;
+        m &= m - 1;
+        if ((j & 3) == 0 && (j >> 2) < n_records) seq_at[(first_read + (j >> 2)) * stride] = file_off + at + i + 1;
+        if (seq_end && (j & 3) == 1 && (j >> 2) < n_records) seq_end[(first_read + (j >> 2)) * stride] = file_off + at + i;
+        j++;
     }
 }
 
@@ -121,7 +114,9 @@ int locate_sequence_lines(hipStream_t s, const u8 *rd_dev, const std::vector<u8>
     if (files.size() % stride) return fail(6, "paired input needs two files per sample");
     std::vector<u64> file_records(files.size());
     std::vector<DBuf<u64> *> blk_offs;
-    struct Guard { std::vector<DBuf<u64> *> &v; ~Guard() { for (auto *p : v) delete p; } } guard{blk_offs};
+    std::vector<DBuf<unsigned short> *> masks;
+    struct Guard { std::vector<DBuf<u64> *> &v; std::vector<DBuf<unsigned short> *> &m;
+                   ~Guard() { for (auto *p : v) delete p; for (auto *p : m) delete p; } } guard{blk_offs, masks};
     u64 n_reads = 0;                                        // records over all samples (pairs count once here)
     for (size_t f = 0; f < files.size(); f++) {
         const auto &fl = files[f];
@@ -131,7 +126,10 @@ int locate_sequence_lines(hipStream_t s, const u8 *rd_dev, const std::vector<u8>
         DBuf<u64> *bo = new DBuf<u64>();
         blk_offs.push_back(bo);
         RCQ(bo->alloc(blocks));
-        hipLaunchKernelGGL(k_nl_count, dim3(blocks), dim3(CT), 0, s, rd_dev + fl.off, fl.bytes, blk.p);
+        DBuf<unsigned short> *mk = new DBuf<unsigned short>();
+        masks.push_back(mk);
+        RCQ(mk->alloc((u64)blocks * CT));
+        hipLaunchKernelGGL(k_nl_count, dim3(blocks), dim3(CT), 0, s, rd_dev + fl.off, fl.bytes, blk.p, mk->p);
         RCQ(scan_u32(s, blk.p, bo->p, blocks, tot_dev));
         u64 n_nl = 0;
         HIPQ(hipMemcpyAsync(&n_nl, tot_dev, 8, hipMemcpyDeviceToHost, s));
@@ -150,7 +148,7 @@ int locate_sequence_lines(hipStream_t s, const u8 *rd_dev, const std::vector<u8>
     for (size_t f = 0; f < files.size(); f++) {
         const auto &fl = files[f];
         const u32 mate = paired ? (u32)(f & 1) : 0u;
-        hipLaunchKernelGGL(k_fq_emit, dim3(grid_of(fl.bytes, CT * 16)), dim3(CT), 0, s, rd_dev + fl.off, fl.bytes, blk_offs[f]->p, fl.off,
+        hipLaunchKernelGGL(k_fq_emit, dim3(grid_of(fl.bytes, CT * 16)), dim3(CT), 0, s, masks[f]->p, fl.bytes, blk_offs[f]->p, fl.off,
                            seq_at.p + mate, seq_end ? seq_end->p + mate : (u64 *)nullptr, first, stride, file_records[f]);
         if (!paired || (f & 1)) first += file_records[f];
     }

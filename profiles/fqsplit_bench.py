@@ -34,9 +34,9 @@ for i in range(4):
         first = st["ms_device"]
     if best is None or st["ms_device"] < best["ms_device"]:
         best = st
-alg = 3 * best["image_bytes"] + 2 * 12 * best["read_mers"] * (1 if groups > 1 else 0) + 12 * best["read_mers"] + best["output_bytes"]
+alg = (best["image_bytes"] * 5 // 4 + best["read_mers"] * (best["record_bytes"] - 8) + 2 * 12 * best["read_mers"] * (1 if groups > 1 else 0) + 12 * best["read_mers"] + best["output_bytes"])
 print("%s, %d groups: %d read-mers -> %d B of fragment files; device %.2f ms (first run %.2f; parse %.2f, classify %.2f, order %.2f, write %.2f), run() wall %.1f ms: "
-      "%.1f M reads/s, %.2f TB/s over the algorithmic bytes (image x 3, records x 1, order pass)" % (
+      "%.1f M reads/s, %.2f TB/s over the algorithmic bytes (image once + its line-end masks written and read, bases once more, 12-byte records, order pass, files out)" % (
           mode, groups, best["read_mers"], best["output_bytes"], best["ms_device"], first, best["ms_parse"], best["ms_classify"], best["ms_order"],
           best["ms_write"], best["wall"], best["reads"] / best["ms_device"] / 1e3, alg / best["ms_device"] / 1e9), flush=True)
 tmp = tempfile.mkdtemp(prefix="cora_fsb_")
