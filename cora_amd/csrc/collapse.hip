@@ -255,6 +255,14 @@ __global__ __launch_bounds__(CT) void k_reads_pack(const u8 *__restrict__ rd, co
             while (run.more()) {
                 u32 cnt;
                 u32 four = run.next(cnt);
+                // four bases at once: ((c >> 1) ^ (c >> 2)) & 3 is the code of A C G T, a byte permute turns the codes back
+                // into letters, and if that gives the input again all four were A C G T
+                const u32 c4 = ((four >> 1) ^ (four >> 2)) & 0x03030303u;
+                if (cnt == 4 && __builtin_amdgcn_perm(0u, ACGT_PACKED, c4) == four) {
+                    code |= (u64)((c4 * 0x40100401u) >> 24) << (56 - 2 * j);
+                    j += 4;
+                    continue;
+                }
                 for (u32 t = 0; t < cnt; t++, j++, four >>= 8) {
                     const u32 c = four & 0xFFu;
                     const u32 v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
