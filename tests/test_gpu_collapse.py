@@ -178,3 +178,30 @@ def test_read_chain_sharded_over_ranks(world, tmp_path):
         n = mcf.mfg.CASES[mcf.CASES[name][0]][2]
         got = [[open(os.path.join(str(tmp_path), "%s.%s.split%d" % (name, fn, g)), "rb").read() for fn in ("reads", "perfect", "lrn")] for g in range(n)]
         check_frag(name, got)
+
+
+@pytest.mark.parametrize("ref,L,split", [("syn", 100, "FULL"), ("fam", 75, "FULL"), ("multi", 60, "FULL"), ("syn", 99, "THREEWAY"),
+                                         ("fam", 150, "FULL"), ("syn", 298, "FULL"), ("multi", 129, "FULL")])
+def test_every_reference_window_groups_as_in_the_oracle(ref, L, split, tmp_path):
+    """No reads at all: the number of distinct reference read-mers must be the oracle's (every window's canonical form and
+    hash take part, not only the windows some read matches), and the same on every repetition."""
+    fq = tmp_path / "none.fq"
+    fq.write_bytes(b"")
+    lst = tmp_path / "list"
+    lst.write_text("1\n%s\t0\n" % fq)
+    fa = os.path.join(helpers.GOLDEN, "inputs", ref + ".fa")
+    o = [str(tmp_path / x) for x in ("r", "p", "l")]
+    r = subprocess.run([build_collapse_oracle(), str(lst), "3", o[0], fa, "60", str(L), o[1], "0", o[2], "SINGLE", split, "GENERIC", "NONE", "0",
+                        str(tmp_path / "k"), "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    want = int(r.stderr.split("distinct")[1].split()[0])
+    got = []
+    for _ in range(3):
+        c = ccol.Collapse(3, L, "SINGLE", split, "GENERIC")
+        c.set_reference(open(fa, "rb").read())
+        c.add_reads(b"")
+        c.run()
+        got.append(c.stats()["distinct"])
+        assert c.outputs() == [b"", b"", b""]
+        c.close()
+    assert got == [want] * 3, (got, want)
