@@ -1,10 +1,13 @@
 // job.hip -- C-ABI of libcora_hip.so (include/cora_hip.h) and the stage orchestration of one
 // table build on one MI355X.  HTS = /root/reference/homTable_setup.cpp.
 #include "job_internal.hpp"
+#include <mutex>
 
 using namespace cora;
 
 extern "C" const char *cora_hip_last_error(void) { return g_err.c_str(); }
+
+static int scratch_ptr_of(int device, void **out);
 
 extern "C" int cora_hip_init(int device)
 {
@@ -18,6 +21,8 @@ extern "C" int cora_hip_init(int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(102, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
     g_device = device;
+    void *sp = nullptr;
+    RCQ(scratch_ptr_of(device, &sp));          // static scratch of cora_hip_radix_sort_noalloc: its address on this GPU
     return 0;
 }
 
@@ -286,6 +291,66 @@ extern "C" int cora_hip_radix_sort(uint64_t *key_hi, uint64_t *key_lo, uint32_t 
     }
     hipError_t e = hipStreamSynchronize(nullptr);
     scratch.release();
+    if (rc || e != hipSuccess) return fail(100, "radix sort failed (%d, %s)", rc, hipGetErrorString(e));
+    return 0;
+}
+
+// ---- the same sort for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc).  No counterpart in the reference.  The per-tile digit histograms and the chunk sums/offsets, which
+// cora_hip_radix_sort keeps in hipMalloc'ed SortScratch memory, live in a file-scope device array; every GPU holds its
+// own copy at its own address (looked up once per device).  Every call on a GPU shares that GPU's array: calls that
+// overlap on one GPU race.  Nothing in it needs to start at zero -- every pass writes each word before reading it.
+constexpr u64 NOALLOC_MAX_RECORDS = 1ull << 24;
+constexpr size_t NOALLOC_TILES = NOALLOC_MAX_RECORDS / RS_TILE_MIN;                   // 4096 tiles of the smallest shape
+constexpr size_t NOALLOC_CHUNKS = (NOALLOC_TILES + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
+constexpr size_t NOALLOC_HIST_BYTES = NOALLOC_TILES * 256 * sizeof(u32);              // 4 MiB
+constexpr size_t NOALLOC_CHUNK_BYTES = 2 * NOALLOC_CHUNKS * 256 * sizeof(u32);        // 128 KiB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_HIST_BYTES + NOALLOC_CHUNK_BYTES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static void *g_scratch_ptr[NOALLOC_MAX_DEVICES];       // device address of `scratch` on each GPU (the array's name is a host-side stand-in)
+static std::mutex g_scratch_mutex;
+
+// device address of this GPU's copy of `scratch`; `device` must be the current device
+static int scratch_ptr_of(int device, void **out)
+{
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return fail(102, "device %d out of range for the static sort scratch", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(100, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
+extern "C" uint64_t cora_hip_radix_sort_noalloc_max(void) { return NOALLOC_MAX_RECORDS; }
+
+extern "C" int cora_hip_radix_sort_noalloc(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val, uint64_t *tmp_hi, uint64_t *tmp_lo,
+                                           uint32_t *tmp_val, uint64_t n, int bit_lo, int bit_hi)
+{
+    if (g_device < 0) return fail(102, "cora_hip_init has not succeeded");
+    if (!key_hi || !tmp_hi || (key_lo && !tmp_lo) || (val && !tmp_val)) return fail(19, "bad sort arguments");
+    if (n > NOALLOC_MAX_RECORDS)
+        return fail(19, "cora_hip_radix_sort_noalloc sorts at most %llu records (static scratch of %zu bytes); got %llu",
+                    (unsigned long long)NOALLOC_MAX_RECORDS, sizeof scratch, (unsigned long long)n);
+    int dev = -1;
+    HIPQ(hipGetDevice(&dev));
+    void *sp = nullptr;
+    RCQ(scratch_ptr_of(dev, &sp));
+    SortScratch sc;                                        // borrows the static array: reserve() never allocates, release() never frees
+    sc.bind_external((u32 *)sp, NOALLOC_TILES, (u32 *)((unsigned char *)sp + NOALLOC_HIST_BYTES), NOALLOC_CHUNKS);
+    SortArrays keys, tmp;
+    keys.a = key_hi; keys.b = key_lo; keys.c = val;
+    tmp.a = tmp_hi; tmp.b = tmp_lo; tmp.c = tmp_val;
+    int rc = radix_sort(nullptr, keys, tmp, n, bit_lo, bit_hi, sc, nullptr);      // untimed: no events are created
+    if (!rc && n && keys.a != key_hi) {       // odd number of passes: bring the result home
+        (void)hipMemcpyAsync(key_hi, keys.a, n * sizeof(u64), hipMemcpyDeviceToDevice, nullptr);
+        if (key_lo) (void)hipMemcpyAsync(key_lo, keys.b, n * sizeof(u64), hipMemcpyDeviceToDevice, nullptr);
+        if (val) (void)hipMemcpyAsync(val, keys.c, n * sizeof(u32), hipMemcpyDeviceToDevice, nullptr);
+    }
+    hipError_t e = hipStreamSynchronize(nullptr);
     if (rc || e != hipSuccess) return fail(100, "radix sort failed (%d, %s)", rc, hipGetErrorString(e));
     return 0;
 }

@@ -300,6 +300,7 @@ int SortScratch::reserve(u64 n)
 {
     size_t tiles = (size_t)((n + RS_TILE_MIN - 1) / RS_TILE_MIN);
     size_t chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
+    if (external && (tiles > cap_tiles || chunks > cap_chunks)) return (int)hipErrorInvalidValue;
     if (tiles > cap_tiles) {
         if (tile_hist) (void)hipFree(tile_hist);
         tile_hist = nullptr; cap_tiles = 0;
@@ -312,7 +313,6 @@ int SortScratch::reserve(u64 n)
         RS_CHECK(hipMalloc(&chunk_sums, 2 * chunks * 256 * sizeof(u32)));     // sums, then offsets
         cap_chunks = chunks;
     }
-    if (!ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&ev[i]));
     if (!xcd_group) {
         xcd_group = 16;
         if (getenv("RS_XCD_GROUP")) xcd_group = (u32)atoi(getenv("RS_XCD_GROUP"));
@@ -321,10 +321,19 @@ int SortScratch::reserve(u64 n)
     return 0;
 }
 
+void SortScratch::bind_external(u32 *hist, size_t tiles, u32 *chunks, size_t chunk_count)
+{
+    release();
+    external = true;
+    tile_hist = hist; cap_tiles = tiles;
+    chunk_sums = chunks; cap_chunks = chunk_count;
+}
+
 void SortScratch::release()
 {
-    if (tile_hist) (void)hipFree(tile_hist);
-    if (chunk_sums) (void)hipFree(chunk_sums);
+    if (tile_hist && !external) (void)hipFree(tile_hist);
+    if (chunk_sums && !external) (void)hipFree(chunk_sums);
+    external = false;
     if (ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
     tile_hist = nullptr; chunk_sums = nullptr; cap_tiles = cap_chunks = 0;
 }
@@ -352,6 +361,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     int pass = 0;
     int rc = scratch.reserve(n);
     if (rc) return rc;
+    if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
     // records with a payload go through 512-thread tiles of 8192 (their 4-byte payload runs are twice as long: +9 % scatter
     // bandwidth), key-only records through 256-thread tiles of 4096 (measured best for each, tools/sortbench.cpp)
     const u32 tile_recs = (keys.c != nullptr) ? 512 * RS_IPT : 256 * RS_IPT;

@@ -31,9 +31,12 @@ struct SortScratch {
     u32 *chunk_sums = nullptr;   // [chunks][256]
     size_t cap_tiles = 0, cap_chunks = 0;
     u32 xcd_group = 0;           // consecutive tiles handed to one XCD by the scatter (0 = not chosen yet)
-    hipEvent_t ev[2 * 16] = {};  // one pair per pass of a sort
+    hipEvent_t ev[2 * 16] = {};  // one pair per pass of a sort (created when a sort is first timed)
+    bool external = false;       // tile_hist / chunk_sums are the caller's memory: never grown, never freed
     int reserve(u64 n);
     void release();
+    // Use caller-owned device memory instead of hipMalloc: hist holds tiles * 256 u32, chunks 2 * chunk_count * 256 u32.
+    void bind_external(u32 *hist, size_t tiles, u32 *chunks, size_t chunk_count);
 };
 
 constexpr int RS_MAX_PASSES = 16;

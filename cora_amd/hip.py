@@ -21,7 +21,7 @@ BIN_DIR = os.path.join(_HERE, "bin")
 EXPORTS = [
     "cora_hip_init", "cora_hip_shutdown", "cora_hip_last_error", "cora_hip_job_create", "cora_hip_job_destroy",
     "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_tables", "cora_hip_job_stats",
-    "cora_hip_radix_sort", "cora_hip_test_sort_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers",
+    "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers",
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
     "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
     "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
@@ -123,6 +123,8 @@ def lib():
         L.cora_hip_job_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.cora_hip_job_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.cora_hip_radix_sort.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_int, C.c_int]
+        L.cora_hip_radix_sort_noalloc.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_int, C.c_int]
+        L.cora_hip_radix_sort_noalloc_max.restype = C.c_uint64
         L.cora_hip_test_sort_host.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_int, C.c_int]
         L.cora_hip_test_list_sort.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.cora_hip_test_pack.argtypes = [C.c_void_p] * 5

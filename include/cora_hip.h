@@ -347,6 +347,18 @@ int cora_hip_radix_sort(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val,
                         uint64_t *tmp_hi, uint64_t *tmp_lo, uint32_t *tmp_val,
                         uint64_t n, int bit_lo, int bit_hi);
 
+/* cora_hip_radix_sort for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments, same result (stable,
+ * sorted records back in the original arrays); the per-tile digit histograms that cora_hip_radix_sort keeps in
+ * hipMalloc'ed memory live in a 4.1 MiB static device array instead, which every GPU the library runs on holds until
+ * the process ends.  Limit: n <= cora_hip_radix_sort_noalloc_max() = 2^24 records; more is refused with status 19.
+ * The call makes no hipMalloc / hipFree / event creation.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU race (serialise them); nothing in the array has to be cleared between calls. */
+int cora_hip_radix_sort_noalloc(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val,
+                                uint64_t *tmp_hi, uint64_t *tmp_lo, uint32_t *tmp_val,
+                                uint64_t n, int bit_lo, int bit_hi);
+uint64_t cora_hip_radix_sort_noalloc_max(void);
+
 /* Host-buffer convenience wrappers for tests: copy in, run the kernels, copy out. */
 int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val, uint64_t n, int bit_lo, int bit_hi);
 /* The device replica of libstdc++'s std::sort with the reference's comparator sort_by_decreasing_blockLen (HTS:1110-1113,
