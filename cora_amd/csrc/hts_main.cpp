@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,8 +71,14 @@ static bool write_file(const std::string &path, const void *data, size_t n)
     return fclose(f) == 0 && ok;
 }
 
+static double ms_since(const std::chrono::steady_clock::time_point &t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 int main(int argc, char **argv)
 {
+    const auto t_start = std::chrono::steady_clock::now();
     if (argc != 10) {
         std::cout << "homTable_setup (MI355X build): exact and inexact homology tables of a reference\n"
                      "  1 reference FASTA (with .fai)   2 read-mer length [33-64]   3 2-char split file\n"
@@ -166,8 +173,10 @@ int main(int argc, char **argv)
     }
     if (fai_len.empty()) { std::cout << "ERROR: empty .fai" << std::endl; return 52; }
 
+    const double ms_parse = ms_since(t_start);
     int rc = cora_hip_init(0);
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
+    const double ms_init = ms_since(t_start);
     // The image is scanned on the GPU (lines, headers, contig lengths: cora_hip_fasta_scan).  A file in the layout
     // ReadReference assumes (HTS:96-142: one line width) is read in place; any other is gathered first, where the
     // reference would silently mis-load it.  The .fai must describe the same contigs.
@@ -194,8 +203,10 @@ int main(int argc, char **argv)
     rc = cora_hip_job_create(&prm, &job);
     if (!rc) rc = cora_hip_job_set_reference_fasta(job, fa);
     cora_hip_fasta_destroy(fa);
+    const double ms_load = ms_since(t_start);
     if (!rc) rc = cora_hip_job_run(job);
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
+    const double ms_build = ms_since(t_start);
 
     const uint8_t *ex, *inx;
     size_t exb, inb;
@@ -220,6 +231,10 @@ int main(int argc, char **argv)
               << st.inexact_nodes << "  (tied lists " << st.dirty_nodes << ", lists > 16 items " << st.big_nodes << ")\n"
               << "ms: pack+keys " << st.ms_pack << "  exact " << st.ms_exact << "  seeds " << st.ms_seeds << "  items " << st.ms_items
               << "  host " << st.ms_host_finish << "  total " << st.ms_total << std::endl;
+    // process start -> the four files closed (SURVEY.md section 8d's definition of the end-to-end time), cumulative marks
+    std::cout << "e2e_ms: args+splits+mmap " << ms_parse << "  device_init " << ms_init - ms_parse << "  read+upload+scan " << ms_load - ms_init
+              << "  build(incl. tables to host) " << ms_build - ms_load << "  write_files " << ms_since(t_start) - ms_build
+              << "  total " << ms_since(t_start) << std::endl;
     cora_hip_job_destroy(job);
     cora_hip_shutdown();
     return 0;

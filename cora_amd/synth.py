@@ -204,6 +204,111 @@ def workload_repeat_rich(seed: int = 5, total_len: int = 100_000_000, max_copies
     return contig
 
 
+# GRCh38 primary assembly: chr1..22, X, Y, M (bases, incl. N)
+GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+                  133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,
+                  64444167, 46709983, 50818468, 156040895, 57227415, 16569]
+GRCH38_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY", "chrM"]
+
+
+def _pairwise_q(div: float) -> float:
+    """Per-base mismatch probability between two copies that were each mutated at rate div from one unit."""
+    return 2 * div * (1 - div) + div * div * 2 / 3
+
+
+def plan_repeat_families(seed: int, young_bases: int, old_bases: int, cand_per_base: float = 3.6):
+    """Repeat families of the GRCh38-like workload as (unit, copies, divergence) lists.
+
+    young: 1-3 % divergence, 4-20 copies (segmental-duplication-like; nearly every window of a copy is within d=2 of its
+    relatives, so these carry the pair output: about copies/2 pairs per base).
+    old: 5-15 % divergence, high copy number (interspersed-repeat-like).  Their copy number is CAPPED: two copies share a
+    16-base seed code with probability (1-q)^16, and every implementation of the reference's semantics -- the reference's
+    chained hash lists (homTable_setup.cpp:2753-2762) included -- compares all members of an equal-code run pairwise, i.e.
+    unit * copies^2 / 2 * (1-q)^16 comparisons per seed.  The cap keeps that at cand_per_base comparisons per repeat base
+    (about 5e9 for the full-size reference, twice what chance collisions of 32-bit codes among 2.9e9 K-mers cost)."""
+    import math
+    rs = np.random.RandomState(seed)
+    young, old = [], []
+    mass = 0
+    while mass < young_bases:
+        unit, copies = int(rs.choice([300, 600, 1200, 2400, 6000])), int(rs.randint(4, 21))
+        young.append((unit, copies, float(rs.uniform(0.01, 0.03))))
+        mass += unit * copies
+    mass = 0
+    while mass < old_bases:
+        unit, div = int(rs.choice([300, 600, 1200, 2400, 6000])), float(rs.uniform(0.05, 0.15))
+        s = (1 - _pairwise_q(div)) ** 16
+        copies = int(max(4, min(cand_per_base / (1.5 * s), 100000)))
+        old.append((unit, copies, div))
+        mass += unit * copies
+    return young, old
+
+
+def workload_grch38_like(seed: int = 38, scale: float = 1.0, young_share: float = 0.05, old_share: float = 0.40,
+                         n_share: float = 0.05):
+    """configs[2]: 25 contigs with the GRCh38 primary-assembly lengths (x scale), 5 % N in runs
+    of >= 10 kbp (telomere ends, one centromere-like run per contig, shorter runs between), 45 % of the bases drawn from
+    repeat families of 300 bp - 6 kbp units (plan_repeat_families: how many families and why the copy numbers are capped),
+    every third copy reverse-complemented, old-family copies soft-masked (lower case) as in the real assembly.
+    -> [(name, uint8 ASCII array)] (views of one array)."""
+    rs = np.random.RandomState(seed)
+    lens = [max(2000, int(round(l * scale))) for l in GRCH38_LENGTHS]
+    total = int(sum(lens))
+    lut = np.zeros(256, dtype=np.uint32)
+    for b in range(256):
+        lut[b] = sum(int(_ACGT[(b >> (2 * k)) & 3]) << (8 * k) for k in range(4))
+    nb = (total + 3) // 4
+    g = lut[np.frombuffer(rs.bytes(nb), dtype=np.uint8)].view(np.uint8)[:total]
+    young, old = plan_repeat_families(seed + 1, int(young_share * total), int(old_share * total))
+    fams = [(u, c, d, False) for u, c, d in young] + [(u, c, d, True) for u, c, d in old]
+    # all instances in one shuffled sequence along the concatenated contigs, random gaps between them
+    inst_len = np.concatenate([np.full(c, u, dtype=np.int64) for u, c, _, _ in fams]) if fams else np.zeros(0, dtype=np.int64)
+    n_inst = len(inst_len)
+    order = rs.permutation(n_inst)
+    free = total - int(inst_len.sum())
+    if n_inst and free > 0:
+        gaps = rs.random_sample(n_inst + 1)
+        gaps = np.floor(gaps / gaps.sum() * free).astype(np.int64)
+        starts_in_order = np.cumsum(gaps[:-1] + np.concatenate([[0], inst_len[order][:-1]]))
+        start = np.empty(n_inst, dtype=np.int64)
+        start[order] = starts_in_order
+        at = 0
+        for unit, copies, div, soft in fams:
+            codes = rs.randint(0, 4, size=unit).astype(np.uint8)
+            m = np.tile(codes, copies)
+            nm = int(rs.binomial(unit * copies, div))
+            idx = rs.randint(0, unit * copies, size=nm)
+            m[idx] = (m[idx] + rs.randint(1, 4, size=nm).astype(np.uint8)) & 3
+            rows = m.reshape(copies, unit)
+            rows[2::3] = 3 - rows[2::3, ::-1]
+            rows = _ACGT[rows]
+            if soft:
+                rows |= 0x20
+            for c in range(copies):
+                a = int(start[at + c])
+                g[a:a + unit] = rows[c]
+            at += copies
+    # N runs: per contig 10 kbp at either end, a centromere-like run of 3 %, shorter runs to n_share in all
+    contigs, off = [], 0
+    min_run = max(100, int(10000 * min(1.0, scale * 50)))
+    for name, ln in zip(GRCH38_NAMES, lens):
+        c = g[off:off + ln]
+        off += ln
+        if ln >= 20 * min_run:
+            c[:min_run] = ord("N"); c[ln - min_run:] = ord("N")
+            cen = int(0.03 * ln)
+            c0 = int(ln * rs.uniform(0.3, 0.5))
+            c[c0:c0 + cen] = ord("N")
+            left = int(n_share * ln) - 2 * min_run - cen
+            while left > 0:
+                run = int(rs.randint(min_run, 5 * min_run + 1))
+                a = int(rs.randint(0, ln - run))
+                c[a:a + run] = ord("N")
+                left -= run
+        contigs.append((name, c))
+    return contigs
+
+
 def ensure_dir(p: str) -> str:
     os.makedirs(p, exist_ok=True)
     return p
