@@ -5,6 +5,9 @@
 
 using namespace cora;
 
+// representatives above which the seed records carry sketches (measured: stages.hip, st_seed_verify)
+constexpr u64 SKETCH_MIN_REPS = 1ull << 28;
+
 extern "C" const char *cora_hip_last_error(void) { return g_err.c_str(); }
 
 static int scratch_ptr_of(int device, void **out);
@@ -201,23 +204,29 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     PairStore ps;
     {
         // every seed's codes in one pass over the representatives, each with its first-digit tile histogram
-        DBuf<u64> codes[CORA_HIP_MAX_SEEDS];
-        DBuf<u32> hists[CORA_HIP_MAX_SEEDS], sketches[CORA_HIP_MAX_SEEDS];
+        DBuf<u64> codes[CORA_HIP_MAX_SEEDS], skb[CORA_HIP_MAX_SEEDS];
+        DBuf<u32> hists[CORA_HIP_MAX_SEEDS], skc[CORA_HIP_MAX_SEEDS];
         u64 *cp[4] = {nullptr, nullptr, nullptr, nullptr};
-        u32 *hp[4] = {nullptr, nullptr, nullptr, nullptr}, *kp[4] = {nullptr, nullptr, nullptr, nullptr};
+        u32 *hp[4] = {nullptr, nullptr, nullptr, nullptr};
+        SeedSketches sk;
+        memset(&sk, 0, sizeof sk);
         // Chance collisions of 32-bit seed codes grow with NR^2 / 2^32: from a few hundred million representatives on they
-        // dominate verification, and a 4-byte sketch carried through the sort pays for itself (k_verify's pre-filter).
-        const bool use_sketch = job->sketch_mode >= 0 ? job->sketch_mode != 0 : NR > (1ull << 30);
-        const u64 tiles = (NR + RS_TILE_MIN - 1) / RS_TILE_MIN;
+        // dominate verification, and carrying the other seeds' codes through the sort (4 d bytes per record) pays for
+        // itself: k_verify then dismisses partners from the sorted records alone, without touching the genome.
+        const bool use_sketch = job->sketch_mode >= 0 ? job->sketch_mode != 0 : NR > SKETCH_MIN_REPS;
+        sk.on = use_sketch;
+        const u32 tile_recs = radix_sort_tile_records(use_sketch && dp.nseeds >= 3, use_sketch && dp.nseeds != 3);
+        const u64 tiles = (NR + tile_recs - 1) / tile_recs;
         for (int q = 0; q < dp.nseeds; q++) {
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
             cp[q] = codes[q].p; hp[q] = hists[q].p;
-            if (use_sketch) { RCQ(sketches[q].alloc(NR)); kp[q] = sketches[q].p; }
+            if (use_sketch && dp.nseeds >= 3) { RCQ(skb[q].alloc(NR)); sk.b[q] = skb[q].p; }
+            if (use_sketch && dp.nseeds != 3) { RCQ(skc[q].alloc(NR)); sk.c[q] = skc[q].p; }
         }
-        launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, kp);
+        launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs);
         for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
-            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, kp[seed - 1]));
-            codes[seed - 1].release(); hists[seed - 1].release(); sketches[seed - 1].release();
+            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, sk.b[seed - 1], sk.c[seed - 1]));
+            codes[seed - 1].release(); hists[seed - 1].release(); skb[seed - 1].release(); skc[seed - 1].release();
         }
         st.hom_pairs = ps.n;
     }

@@ -152,7 +152,7 @@ struct cora_hip_job {
     HBuf<int16_t> h_blen;
     int host_threads = 8;
     struct ShardState *shard = nullptr;   // multi-GPU stage state (shard.hip)
-    int sketch_mode = -1;         // -1 = by size (on above 2^30 representatives); CORA_SKETCH=0/1 overrides
+    int sketch_mode = -1;         // -1 = by size (job.hip: SKETCH_MIN_REPS); CORA_SKETCH=0/1 overrides
     int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
     ByteBuf exact_bytes, inexact_bytes;
     cora_hip_stats stats;
@@ -237,7 +237,7 @@ int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p);
 int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &host_ms);
 int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBuf<u32> &reps, u64 &n_out);
 int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist = nullptr,
-                   u32 *sketch = nullptr /* [n] per-record sketches for k_verify's pre-filter; sorted along */);
+                   u64 *sk_b = nullptr, u32 *sk_c = nullptr /* [n] per-record sketches for k_verify's pre-filter; sorted along */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
 int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_t n_contigs, u32 W, size_t image_bytes,

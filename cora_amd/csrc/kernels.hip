@@ -826,12 +826,19 @@ __device__ __forceinline__ u32 seed_code_fixed(u64 hi, u64 tail, int s /*0-based
 // All seeds of a run in one pass over the representatives: one window load, NS codes, and -- because a block covers
 // exactly one 4096-record tile of the key-only sort -- the per-tile histogram of each code array's first sort digit
 // (bits 32..39 of the record = low byte of the code), which saves that sort its first histogram pass.
+//
+// Sketch of a record of seed s (optional): the codes of ALL the other seeds, s+1, s+2, ... (cyclically), in the
+// orientation that made this seed's code canonical (the code of seed s' of the reverse complement is rc_code of the
+// forward one: seeds are mirror-symmetric position sets, HTS:2015-2066).  Two records with the same canonical, non-
+// palindromic code are the same K-mer positions in that orientation, so the number of differing bases between their
+// sketches is exactly the number of mismatches inside the other seeds: k_verify dismisses a partner on it without
+// touching the genome.  For K = 50, d = 2 the three seeds cover 48 of the 50 bases.  Layout: NS = 2: one code in skc;
+// NS = 3: two codes in skb (first other seed in the high word); NS = 4: two in skb, the third in skc.
 template <int NS>
 __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ reps, u64 n_reps,
                                                         u64 *__restrict__ out0, u64 *__restrict__ out1, u64 *__restrict__ out2,
                                                         u64 *__restrict__ out3, u32 *__restrict__ hist0, u32 *__restrict__ hist1,
-                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3, u32 *__restrict__ sk0,
-                                                        u32 *__restrict__ sk1, u32 *__restrict__ sk2, u32 *__restrict__ sk3)
+                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3, SeedSketches sk, int per_thread)
 {
     __shared__ u32 h[NS][256];
     const int tid = threadIdx.x;
@@ -839,10 +846,9 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
     for (int s = 0; s < NS; s++) h[s][tid] = 0;
     __syncthreads();
     u64 *const outs[4] = {out0, out1, out2, out3};
-    u32 *const sks[4] = {sk0, sk1, sk2, sk3};
-    const u64 base = (u64)blockIdx.x * 4096;
+    const u64 base = (u64)blockIdx.x * 256 * per_thread;    // one tile of the sort that follows (16 or 32 records per thread)
 #pragma unroll 4
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < per_thread; k++) {
         const u64 r = base + (u64)k * 256 + tid;
         if (r >= n_reps) break;
         const u32 g = reps[r];
@@ -850,18 +856,24 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
         load_window(p, pk, g, hi, lo);
         const int sh = 128 - 2 * p.K;                     // 0 .. 62
         const u64 tail = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-        u32 fwc[NS];
+        u32 fwc[NS], rcc[NS];
 #pragma unroll
-        for (int s = 0; s < NS; s++) fwc[s] = seed_code_fixed<NS>(hi, tail, s, p.seed_q);
+        for (int s = 0; s < NS; s++) { fwc[s] = seed_code_fixed<NS>(hi, tail, s, p.seed_q); rcc[s] = rc_code(fwc[s]); }
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            const u32 fw = fwc[s], rc = rc_code(fw);
-            const u32 c = fw <= rc ? fw : rc;
+            const bool fwd = fwc[s] <= rcc[s];
+            const u32 c = fwd ? fwc[s] : rcc[s];
             outs[s][r] = ((u64)c << 32) | g;
             atomicAdd(&h[s][c & 255u], 1u);
-            // sketch of the record: the NEXT seed's code in the orientation that made this code canonical.  Two K-mers
-            // within d mismatches whose seed s agrees differ in at most d bases of it (k_verify's pre-filter).
-            if (sks[s]) { const u32 o = fwc[(s + 1) % NS]; sks[s][r] = fw <= rc ? o : rc_code(o); }
+            if (sk.on) {
+                const u32 o1 = fwd ? fwc[(s + 1) % NS] : rcc[(s + 1) % NS];
+                if (NS == 2) sk.c[s][r] = o1;
+                else {
+                    const u32 o2 = fwd ? fwc[(s + 2) % NS] : rcc[(s + 2) % NS];
+                    sk.b[s][r] = ((u64)o1 << 32) | o2;
+                    if (NS == 4) sk.c[s][r] = fwd ? fwc[(s + 3) % NS] : rcc[(s + 3) % NS];
+                }
+            }
         }
     }
     __syncthreads();
@@ -901,123 +913,225 @@ __device__ __forceinline__ u32 judge(const DevParams &p, Mism m, int seed, u32 d
     return meta_pack(dir, o1, o2, o3, (u32)(seed - 1), 0, 0);
 }
 
-// Which records of the code-sorted list have anything to meet: every member of an equal-code run except
-// its first, plus every record with a palindromic code (it meets itself, Q1).  On a random genome that is
-// about 1.5 % of the records, one per wave: the verification kernels therefore run over the compacted list
-// of such records (all 64 lanes busy with gathers) instead of over all records.
-__global__ __launch_bounds__(256) void k_active_count(const u64 *__restrict__ codes, u64 n_reps, u32 *__restrict__ blk_active,
-                                                      u64 *__restrict__ act_mask)
-{
-    __shared__ u32 ws[4];
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    bool act = false;
-    if (i < n_reps) {
-        const u32 code = (u32)(codes[i] >> 32);
-        act = (i > 0 && (u32)(codes[i - 1] >> 32) == code) || rc_code(code) == code;
-    }
-    const u64 bal = __ballot(act);
-    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = (u32)__popcll(bal); act_mask[i >> 6] = bal; }   // one word per wave
-    __syncthreads();
-    if (threadIdx.x == 0) blk_active[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// second pass: positions of the set bits, from the wave masks alone (the codes are not read again): one thread per
-// mask word = 64 records; blk_off counts per 4 words (the counting pass's blocks)
-__global__ __launch_bounds__(256) void k_active_emit(const u64 *__restrict__ act_mask, u64 n_words, const u64 *__restrict__ blk_off,
-                                                     u32 *__restrict__ active)
-{
-    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (w >= n_words) return;
-    u64 bal = act_mask[w];
-    if (!bal) return;
-    u64 at = blk_off[w >> 2];
-    for (u64 v = w & ~3ull; v < w; v++) at += (u32)__popcll(act_mask[v]);
-    while (bal) {
-        const int b = __ffsll((long long)bal) - 1;
-        active[at++] = (u32)(w * 64 + b);
-        bal &= bal - 1;
-    }
-}
-
-// One thread per active record i (k-mer 1).  It is compared with every EARLIER record of its equal-code
-// run (HTS:2753-2762: k-mer 1 is the later one).  The orientation is the one in which the seed positions
-// agree; a palindromic code agrees in both, and the reference then compares both ways and meets every
-// earlier entry twice (Q1, HTS:2769-2792).
+// Pair verification over the code-sorted records of one seed (HTS:2671-2800, 2138-2265), in three steps.
 //
-// Two passes and no atomics (a counter bumped once per wave was 12 ns x 10^6 waves = most of the first
-// profile): WRITE=false stores each thread's record and comparison counts, the counts are scanned, WRITE=true
-// repeats the comparisons and stores the records at the scanned offsets.  The record order is deterministic:
-// by (code, position) of k-mer 1, then later partners first.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_verify(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ codes,
-                                                const u32 *__restrict__ active, u32 n_active, int seed, u32 *__restrict__ cnt_recs,
-                                                u32 *__restrict__ cnt_cand, const u64 *__restrict__ rec_off, PairRec *__restrict__ pairs,
-                                                const u32 *__restrict__ sketch)
+// 1. k_candidates: every record i (k-mer 1) meets every EARLIER record of its equal-code run (HTS:2753-2762: k-mer 1 is
+//    the later one).  A workgroup streams a tile of VT_TILE consecutive records (plus the VT_HALO records before it) into
+//    LDS with coalesced loads and every thread walks back from its records inside LDS; a run that reaches beyond the halo
+//    is followed into global memory.  Nothing is gathered here: on a GRCh38-sized reference most records have a chance
+//    partner (2.9e9 records, 2^31 canonical codes), so the walk itself is the work, and a lane that went to the genome
+//    for one partner would stall its 63 neighbours for a memory round trip.  What a walk finds worth a look at the
+//    genome is written out as a SLOT (k-mer 1, k-mer 2, kind).
+//    Sketches (sk_b / sk_c, sorted along with the codes; either may be null): the other seeds' codes in the orientation
+//    of the canonical code (k_seed_codes_all).  Their differing bases ARE the mismatches inside those seeds; a partner
+//    with more than d of them cannot be reported (HTS:2138-2265 aborts at > d) and gets no slot.
+//    Two passes and no global atomics: WRITE=false stores each thread's slot count and each workgroup's slot / comparison
+//    sums, the workgroup sums are scanned, WRITE=true repeats the tiles that have slots and stores them.
+//    Skew: the members of a long run (a repeat family whose copies share a seed) sit side by side, so the lanes of a
+//    wave walk the same stretch together; their slots are judged by as many threads as there are slots.
+// 2. k_judge: one thread per slot reads both K-mers from the packed genome and applies CompareAndReport (HTS:2138-2265);
+//    the slot's kind becomes the pair's meta word, or SLOT_NONE.
+// 3. k_slot_count / k_slot_compact: the reported pairs, compacted behind the earlier seeds' records.
+//
+// Slot kinds.  The orientation in which two K-mers are compared is the one in which the seed positions agree; a
+// palindromic code agrees in both, and the reference then compares both ways, meets every earlier entry twice and
+// starts with the K-mer itself (Q1, HTS:2769-2792): kinds 1-4 are the (orientation, copy) cases of such a pair, 5 the
+// self comparison.  The order of the records is deterministic; nothing downstream depends on it: items are sorted by
+// (source, target) and lists with tied targets are finished in the reference's discovery order, recomputed per item.
+constexpr int VT_PER = 8;
+constexpr int VT_TILE = 256 * VT_PER;        // records per workgroup
+constexpr int VT_HALO = 512;                 // records before the tile kept in LDS as well
+constexpr u32 SLOT_NONE = 0xFFFFFFFFu;
+enum { SLOT_PLAIN = 0, SLOT_PAL_FWD0, SLOT_PAL_FWD1, SLOT_PAL_REV0, SLOT_PAL_REV1, SLOT_PAL_SELF };
+
+template <bool WRITE, bool SKB, bool SKC>
+__global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__restrict__ codes, u64 n, u32 *__restrict__ cnt_slots /* [blocks * 256] */,
+                                                    u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
+                                                    PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c)
 {
-    constexpr u32 INV = 0xFFFFFFFFu;
-    const u32 t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_active) return;
-    if (WRITE && cnt_recs[t] == 0) return;                  // the counting pass found nothing to report here: no second look at the genome
-    const u64 i = active[t];
-    u32 nrec = 0, ncand = 0;
-    u64 at = WRITE ? rec_off[t] : 0;
-    const u64 ci = codes[i];
-    const u32 code = (u32)(ci >> 32), gi = (u32)ci;
-    const bool pal = rc_code(code) == code;
-    u64 ih = 0, il = 0;
-    bool have_i = false;                                    // k-mer 1 is fetched when the first partner needs it
-    const u64 smh = p.seedmask_hi[seed - 1], sml = p.seedmask_lo[seed - 1];
-    // Pre-filter (large references: random code collisions grow with N^2 / 2^32): the sketches of two records that
-    // can be reported differ in at most d bases, so most chance partners are dismissed without touching the genome.
-    const bool filter = sketch != nullptr && !pal;
-    const u32 ski = filter ? sketch[i] : 0u;
-    if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
-        load_window(p, pk, gi, ih, il);
-        have_i = true;
-        u64 rh, rl;
-        rc_window(p.K, ih, il, rh, rl);
-        const u32 mr = judge(p, mism_of(ih, il, rh, rl), seed, 1);
-        ncand++;
-        if (mr != INV) {
-            if (WRITE) { pairs[at].p1 = gi; pairs[at].p2 = gi; pairs[at].meta = mr | (1u << 24); at++; }
-            else nrec++;
+    __shared__ u64 s_key[VT_TILE + VT_HALO];
+    __shared__ u64 s_b[SKB ? VT_TILE + VT_HALO : 1];
+    __shared__ u32 s_c[SKC ? VT_TILE + VT_HALO : 1];
+    __shared__ u32 l4[4];
+    __shared__ u64 c4[4];
+    const int tid = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * VT_TILE;
+    u64 at = 0;
+    u32 mine = 1;
+    if (WRITE) {
+        if (blk_slots[blockIdx.x] == 0) return;              // the counting pass found nothing worth a look in this tile (uniform)
+        mine = cnt_slots[(u64)blockIdx.x * 256 + tid];
+        at = blk_off[blockIdx.x] + block_excl_scan_u32(mine, l4, nullptr);
+    }
+    const u64 lo = base >= (u64)VT_HALO ? base - VT_HALO : 0;       // first record held in LDS, at slot `first`
+    const int first = (int)(VT_HALO - (base - lo));
+    const u64 hi = base + VT_TILE < n ? base + VT_TILE : n;
+    {
+        // every load of the tile is issued before the first is used (one load -> one LDS store at a time left the
+        // workgroup waiting for ten memory round trips in a row)
+        constexpr int LD = (VT_TILE + VT_HALO) / 256;
+        u64 rk[LD], rb[SKB ? LD : 1];
+        u32 rc[SKC ? LD : 1];
+#pragma unroll
+        for (int q = 0; q < LD; q++) {
+            const u64 g = lo + (u64)(q * 256 + tid);
+            const bool in = g < hi;
+            rk[q] = in ? __builtin_nontemporal_load(codes + g) : 0ull;
+            if (SKB) rb[q] = in ? __builtin_nontemporal_load(sk_b + g) : 0ull;
+            if (SKC) rc[q] = in ? __builtin_nontemporal_load(sk_c + g) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < LD; q++) {
+            const int slot = first + q * 256 + tid;
+            if (slot < VT_TILE + VT_HALO) {
+                s_key[slot] = rk[q];
+                if (SKB) s_b[slot] = rb[q];
+                if (SKC) s_c[slot] = rc[q];
+            }
         }
     }
-    for (u64 j = i; j-- > 0;) {
-        const u64 cj = codes[j];
-        if ((u32)(cj >> 32) != code) break;
-        const u32 gj = (u32)cj;
-        if (filter) {
-            const u32 x = ski ^ sketch[j];
-            if (__popc((x | (x >> 1)) & 0x55555555u) > p.d) { ncand++; continue; }      // still a comparison the reference makes
+    __syncthreads();
+    const bool have_sk = SKB || SKC;
+    u32 nslot = 0;
+    u64 ncand = 0;
+#pragma unroll 1
+    for (int k = 0; k < (mine ? VT_PER : 0); k++) {         // (second pass: a thread without slots does not walk again)
+        const int li = VT_HALO + k * 256 + tid;
+        if (base + (u64)(k * 256 + tid) >= n) break;
+        const u64 ci = s_key[li];
+        const u32 code = (u32)(ci >> 32), gi = (u32)ci;
+        // the record before this one is in LDS too (slot li - 1 >= first) unless this is record 0 of the whole list
+        const bool has_prev = li > first && (u32)(s_key[li - 1] >> 32) == code;
+        const bool pal = rc_code(code) == code;
+        if (!has_prev && !pal) continue;
+        const bool filter = have_sk && !pal;
+        const u64 bi = (filter && SKB) ? s_b[li] : 0ull;
+        const u32 qi = (filter && SKC) ? s_c[li] : 0u;
+        u32 nc = 0;                                             // comparisons of this record (added to ncand below)
+        if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
+            nc++;
+            if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gi; slots[at].meta = SLOT_PAL_SELF; at++; }
+            else nslot++;
         }
-        if (!have_i) { load_window(p, pk, gi, ih, il); have_i = true; }
-        u64 jh, jl, rh, rl;
-        load_window(p, pk, gj, jh, jl);
+        // one earlier record of the run (HTS:2753-2762): a comparison the reference makes, and perhaps a slot
+        auto visit = [&](u32 gj, u64 bj, u32 qj) {
+            if (pal) {
+                nc += 4;
+                if (WRITE) for (u32 c = SLOT_PAL_FWD0; c <= SLOT_PAL_REV1; c++, at++) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = c; }
+                else nslot += 4;
+                return;
+            }
+            nc++;                                               // whatever the sketches say
+            if (filter) {
+                int mm = 0;
+                if (SKB) { const u64 x = bi ^ bj; mm += __popcll((x | (x >> 1)) & M55); }
+                if (SKC) { const u32 y = qi ^ qj; mm += __popc((y | (y >> 1)) & 0x55555555u); }
+                if (mm > p.d) return;
+            }
+            if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = SLOT_PLAIN; at++; }
+            else nslot++;
+        };
+        // walk back inside LDS: slots li-1 .. first  (a tight loop of its own: the common case)
+        int j = li - 1;
+        bool more = has_prev;
+        while (more) {
+            visit((u32)s_key[j], SKB ? s_b[j] : 0ull, SKC ? s_c[j] : 0u);
+            j--;
+            more = j >= first && (u32)(s_key[j] >> 32) == code;
+        }
+        ncand += nc;
+        // a run that reaches the start of the halo may go on in global memory: records lo-1 .. 0
+        if (has_prev && j < first && lo > 0) {
+            for (u64 g = lo; g-- > 0;) {
+                const u64 cj = codes[g];
+                if ((u32)(cj >> 32) != code) break;
+                nc = 0;
+                visit((u32)cj, SKB ? sk_b[g] : 0ull, SKC ? sk_c[g] : 0u);
+                ncand += nc;
+            }
+        }
+    }
+    if (!WRITE) {
+        cnt_slots[(u64)blockIdx.x * 256 + tid] = nslot;
+        u32 r = nslot;
+        u64 c = ncand;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o, 64); c += __shfl_xor(c, o, 64); }
+        if ((tid & 63) == 0) { l4[tid >> 6] = r; c4[tid >> 6] = c; }
+        __syncthreads();
+        if (tid == 0) {
+            blk_slots[blockIdx.x] = l4[0] + l4[1] + l4[2] + l4[3];
+            blk_cand[blockIdx.x] = c4[0] + c4[1] + c4[2] + c4[3];
+        }
+    }
+}
+
+// One thread per slot: both K-mers from the packed genome, CompareAndReport; meta in place of the kind.  Also counts the
+// reported pairs per block of 256 slots (for the compaction).
+__global__ __launch_bounds__(256) void k_judge(DevParams p, const u64 *__restrict__ pk, PairRec *__restrict__ slots, u64 n_slots, int seed,
+                                               u32 *__restrict__ blk_valid)
+{
+    __shared__ u32 l4[4];
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 meta = SLOT_NONE;
+    if (t < n_slots) {
+        const PairRec r = slots[t];
+        u64 ih, il, jh, jl, rh, rl;
+        load_window(p, pk, r.p1, ih, il);
+        if (r.meta == SLOT_PAL_SELF) { jh = ih; jl = il; } else load_window(p, pk, r.p2, jh, jl);
         rc_window(p.K, jh, jl, rh, rl);
         const Mism same = mism_of(ih, il, jh, jl), rev = mism_of(ih, il, rh, rl);
-        u32 mf = INV, mr = INV, mr_extra = 0;
-        if (pal) {
-            ncand += 4;
-            mf = judge(p, same, seed, 0);
-            mr = judge(p, rev, seed, 1);
-            mr_extra = 1u << 24;
-        } else {
-            ncand++;
-            const bool same_ok = ((same.hi & smh) | (same.lo & sml)) == 0;
-            if (same_ok) mf = judge(p, same, seed, 0); else mr = judge(p, rev, seed, 1);
+        switch (r.meta) {
+        case SLOT_PLAIN: {
+            const bool same_ok = ((same.hi & p.seedmask_hi[seed - 1]) | (same.lo & p.seedmask_lo[seed - 1])) == 0;
+            meta = same_ok ? judge(p, same, seed, 0) : judge(p, rev, seed, 1);
+            break;
         }
-        const u32 copies = pal ? 2u : 1u;                   // palindromic code: every record twice (Q1)
-        if (mf != INV) {
-            if (WRITE) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mf | (c << 25); }
-            else nrec += copies;
+        case SLOT_PAL_FWD0: case SLOT_PAL_FWD1:
+            meta = judge(p, same, seed, 0);
+            if (meta != SLOT_NONE) meta |= (r.meta - SLOT_PAL_FWD0) << 25;
+            break;
+        case SLOT_PAL_REV0: case SLOT_PAL_REV1:
+            meta = judge(p, rev, seed, 1);
+            if (meta != SLOT_NONE) meta |= (1u << 24) | ((r.meta - SLOT_PAL_REV0) << 25);
+            break;
+        default:                                                // SLOT_PAL_SELF
+            meta = judge(p, rev, seed, 1);
+            if (meta != SLOT_NONE) meta |= 1u << 24;
+            break;
         }
-        if (mr != INV) {
-            if (WRITE) for (u32 c = 0; c < copies; c++, at++) { pairs[at].p1 = gi; pairs[at].p2 = gj; pairs[at].meta = mr | mr_extra | (c << 25); }
-            else nrec += copies;
-        }
+        slots[t].meta = meta;
     }
-    if (!WRITE) { cnt_recs[t] = nrec; cnt_cand[t] = ncand; }
+    const u64 bal = __ballot(meta != SLOT_NONE);
+    if ((threadIdx.x & 63) == 0) l4[threadIdx.x >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_valid[blockIdx.x] = l4[0] + l4[1] + l4[2] + l4[3];
+}
+
+__global__ __launch_bounds__(256) void k_slot_compact(const PairRec *__restrict__ slots, u64 n_slots, const u64 *__restrict__ blk_off,
+                                                      PairRec *__restrict__ pairs)
+{
+    __shared__ u32 l4[4];
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    PairRec r;
+    r.meta = SLOT_NONE;
+    if (t < n_slots) r = slots[t];
+    const bool ok = r.meta != SLOT_NONE;
+    const u32 pre = block_excl_scan_u32(ok ? 1u : 0u, l4, nullptr);
+    if (ok) pairs[blk_off[blockIdx.x] + pre] = r;
+}
+
+// out += sum of in[0..n)  (few blocks, one atomic each)
+__global__ __launch_bounds__(256) void k_sum_u64(const u64 *__restrict__ in, u64 n, unsigned long long *out)
+{
+    __shared__ u64 c4[4];
+    u64 s = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) s += in[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) c4[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { s = c4[0] + c4[1] + c4[2] + c4[3]; if (s) atomicAdd(out, (unsigned long long)s); }
 }
 
 // ------------------------------------------------------------------ directed items
@@ -1648,36 +1762,52 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
     if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
 }
 void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
-                           u32 *const sk[4])
+                           const SeedSketches &sk, u32 tile_records)
 {
     if (!n_reps) return;
-    const dim3 g((unsigned)((n_reps + 4095) / 4096));
+    const dim3 g((unsigned)((n_reps + tile_records - 1) / tile_records));
+    const int per_thread = (int)(tile_records / 256);
     switch (p.nseeds) {
-    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk[0], sk[1], sk[2], sk[3]); break;
-    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk[0], sk[1], sk[2], sk[3]); break;
-    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk[0], sk[1], sk[2], sk[3]); break;
+    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread); break;
+    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread); break;
+    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread); break;
     }
 }
-void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active, u64 *act_mask)
+u64 verify_blocks(u64 n) { return (n + VT_TILE - 1) / VT_TILE; }
+template <bool WRITE>
+static void launch_candidates(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                              const u64 *blk_off, PairRec *slots, const u64 *sk_b, const u32 *sk_c)
 {
-    if (n_reps) hipLaunchKernelGGL(k_active_count, grid_for(n_reps), dim3(256), 0, s, codes, n_reps, blk_active, act_mask);
+    if (!n) return;
+    const dim3 g((unsigned)verify_blocks(n)), b(256);
+    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates<WRITE, true, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
+    else if (sk_b) hipLaunchKernelGGL((k_candidates<WRITE, true, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
+    else if (sk_c) hipLaunchKernelGGL((k_candidates<WRITE, false, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
+    else hipLaunchKernelGGL((k_candidates<WRITE, false, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
 }
-void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u64 *blk_off, u32 *active)
+void launch_candidates_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                             const u64 *sk_b, const u32 *sk_c)
 {
-    const u64 n_words = (n_reps + 63) >> 6;
-    if (n_reps) hipLaunchKernelGGL(k_active_emit, grid_for(n_words), dim3(256), 0, s, act_mask, n_words, blk_off, active);
+    launch_candidates<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c);
 }
-void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
-                         u32 *cnt_recs, u32 *cnt_cand, const u32 *sketch)
+void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, const u64 *blk_off,
+                             PairRec *slots, const u64 *sk_b, const u32 *sk_c)
 {
-    if (n_active) hipLaunchKernelGGL((k_verify<false>), grid_for(n_active), dim3(256), 0, s, p, pk, codes, active, n_active, seed, cnt_recs,
-                                     cnt_cand, (const u64 *)nullptr, (PairRec *)nullptr, sketch);
+    launch_candidates<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c);
 }
-void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active, int seed,
-                         const u64 *rec_off, u32 *cnt_recs, PairRec *pairs, const u32 *sketch)
+void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid)
 {
-    if (n_active) hipLaunchKernelGGL((k_verify<true>), grid_for(n_active), dim3(256), 0, s, p, pk, codes, active, n_active, seed,
-                                     cnt_recs, (u32 *)nullptr, rec_off, pairs, sketch);
+    if (n_slots) hipLaunchKernelGGL(k_judge, grid_for(n_slots), dim3(256), 0, s, p, pk, slots, n_slots, seed, blk_valid);
+}
+void launch_slot_compact(hipStream_t s, const PairRec *slots, u64 n_slots, const u64 *blk_off, PairRec *pairs)
+{
+    if (n_slots) hipLaunchKernelGGL(k_slot_compact, grid_for(n_slots), dim3(256), 0, s, slots, n_slots, blk_off, pairs);
+}
+void launch_sum_u64(hipStream_t s, const u64 *in, u64 n, u64 *out)
+{
+    if (!n) return;
+    const u64 blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_sum_u64, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, s, in, n, (unsigned long long *)out);
 }
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta)
 {

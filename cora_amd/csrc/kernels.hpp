@@ -93,15 +93,23 @@ void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const 
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off,
                         const u32 *ent, const u8 *ent_dir, u8 *merge_prev);
 void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, int seed, u64 *out);
-// every seed's (code, position) records at once + the first-digit tile histogram of each (tiles of 4096 records)
+// every seed's (code, position) records at once + the first-digit tile histogram of each (one block per tile of the sort)
+// per-seed sketch arrays (k_seed_codes_all): b = two other seeds' codes (nseeds >= 3), c = one more code (nseeds 2 and 4)
+struct SeedSketches { int on; u64 *b[4]; u32 *c[4]; };
 void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
-                           u32 *const sketch[4] /* entries may be null */);
-void launch_active_count(hipStream_t s, const u64 *codes, u64 n_reps, u32 *blk_active, u64 *act_mask /* [ceil(n/256)*4] */);
-void launch_active_emit(hipStream_t s, const u64 *act_mask, u64 n_reps, const u64 *blk_off, u32 *active);
-void launch_verify_count(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,
-                         int seed, u32 *cnt_recs, u32 *cnt_cand, const u32 *sketch /* sorted with the codes, or null */);
-void launch_verify_write(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *codes, const u32 *active, u32 n_active,
-                         int seed, const u64 *rec_off, u32 *cnt_recs, PairRec *pairs, const u32 *sketch);
+                           const SeedSketches &sk, u32 tile_records /* radix_sort_tile_records() of the record shape */);
+// Pair verification over the n code-sorted records of one seed (kernels.hip: k_candidates, k_judge, k_slot_compact).
+// candidates: one workgroup per tile of records; cnt_slots[verify_blocks(n) * 256] per thread, blk_slots / blk_cand per
+// workgroup; sk_*: the sketches, sorted with the codes, or null.  judge: slots -> pair records or none, in place, and
+// the reported pairs per block of 256 slots.  compact: those pairs at blk_off (scan of blk_valid) + rank in the block.
+u64 verify_blocks(u64 n);
+void launch_candidates_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                             const u64 *sk_b, const u32 *sk_c);
+void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots,
+                             const u64 *blk_off /* scan of blk_slots */, PairRec *slots, const u64 *sk_b, const u32 *sk_c);
+void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid /* [ceil(n_slots / 256)] */);
+void launch_slot_compact(hipStream_t s, const PairRec *slots, u64 n_slots, const u64 *blk_off, PairRec *pairs);
+void launch_sum_u64(hipStream_t s, const u64 *in, u64 n, u64 *out /* device, accumulated into */);
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta);
 void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr);
 void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start);

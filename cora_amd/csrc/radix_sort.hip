@@ -205,6 +205,14 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
             cv[r] = (li < count) ? __builtin_nontemporal_load(c_in + base + li) : 0;
         }
     }
+    u64 ov[HAS_B ? RS_IPT : 1];             // so is the other key word
+    if (HAS_B) {
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) {
+            u32 li = l0 + r * 64;
+            ov[r] = (li < count) ? __builtin_nontemporal_load(oth_in + base + li) : 0;
+        }
+    }
     for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0;
     __syncthreads();
 
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            if (li < count) stage[lpos[r]] = oth_in[base + li];
+            if (li < count) stage[lpos[r]] = ov[r];
         }
         __syncthreads();
 #pragma unroll
@@ -295,6 +303,8 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
         }
     }
 }
+
+u32 radix_sort_tile_records(bool has_b, bool has_c) { (void)has_b; return has_c ? 512 * RS_IPT : 256 * RS_IPT; }
 
 int SortScratch::reserve(u64 n)
 {
@@ -342,11 +352,12 @@ template <bool HAS_B, bool HAS_C>
 static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
                            int shift, u32 mask, const u32 *tile_off, u32 xg)
 {
+    constexpr int T = HAS_C ? 512 : 256;
     if (HAS_B && dig_b)
-        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, (HAS_C ? 512 : 256)>), dim3(tiles), dim3(HAS_C ? 512 : 256), 0, s, in.a, in.b, in.c, out.a, out.b,
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
                            out.c, n, shift, mask, tile_off, xg);
     else
-        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, (HAS_C ? 512 : 256)>), dim3(tiles), dim3(HAS_C ? 512 : 256), 0, s, in.a, in.b, in.c, out.a, out.b,
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
                            out.c, n, shift, mask, tile_off, xg);
 }
 
@@ -362,9 +373,11 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     int rc = scratch.reserve(n);
     if (rc) return rc;
     if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
-    // records with a payload go through 512-thread tiles of 8192 (their 4-byte payload runs are twice as long: +9 % scatter
-    // bandwidth), key-only records through 256-thread tiles of 4096 (measured best for each, tools/sortbench.cpp)
-    const u32 tile_recs = (keys.c != nullptr) ? 512 * RS_IPT : 256 * RS_IPT;
+    // records with a 4-byte payload go through 512-thread tiles of 8192 (their payload runs are twice as long: +9 % scatter
+    // bandwidth; tools/spreadwrite.cpp shows what short unaligned runs cost: 3.8 TB/s at 136 B, 4.6 at 264 B), all others
+    // through 256-thread tiles of 4096: two-word records need 140 VGPRs, which leaves 512-thread workgroups one per CU
+    // (measured at 2.9e9 records: 30.3 ms per pass against 27.1)
+    const u32 tile_recs = radix_sort_tile_records(keys.b != nullptr, keys.c != nullptr);
     const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
     const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
     const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
@@ -376,7 +389,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const int shift = has_b ? (bit & 63) : bit;
         const u64 *word = dig_b ? keys.b : keys.a;
         u32 *th = scratch.tile_hist;
-        if (pass == 0 && first_hist && !has_b && !has_c) th = first_hist;          // the producer already counted this digit
+        if (pass == 0 && first_hist) th = first_hist;                    // the producer already counted this digit (tiles of radix_sort_tile_records())
         else if (has_c) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th);
         else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th);
         hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums);

@@ -49,8 +49,9 @@ constexpr int RS_CHUNK_TILES = 64;                // tiles per column-scan workg
 // bit_lo is rounded down to a multiple of 8).  Stable.  `keys` and `tmp` are
 // ping-pong buffers of equal shape; on return `keys` names the sorted data
 // (the two structs are swapped after an odd number of passes).
-// first_hist (optional, key-only records): the [tiles of RS_TILE_MIN][256] histogram of the first pass's digit, already
+// first_hist (optional): the [tiles of radix_sort_tile_records()][256] histogram of the first pass's digit, already
 // computed by whoever produced the records; it is consumed (turned into offsets in place).
+u32 radix_sort_tile_records(bool has_b, bool has_c);      // records per tile for that record shape
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi,
                SortScratch &scratch, SortTiming *timing, u32 *first_hist = nullptr);
 

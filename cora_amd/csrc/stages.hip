@@ -230,43 +230,53 @@ int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBu
 
 // One seed: sort the (code, position) records, compact the run members, verify, append the pair records
 // (HTS:2671-2800, 2138-2265).  codes holds n records in which equal codes appear in increasing position.
-int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u32 *sketch)
+// sk_b / sk_c: the records' sketches (k_seed_codes_all), sorted along with them; either or both may be null.
+int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u64 *sk_b, u32 *sk_c)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
     if (!n) return 0;
-    DBuf<u64> codes_tmp, blk_off, scr, tots;
-    DBuf<u32> blk_active;
-    const u32 vb = (u32)((n + 255) / 256);
-    DBuf<u64> act_mask;
-    RCQ(codes_tmp.alloc(n)); RCQ(blk_active.alloc(vb)); RCQ(blk_off.alloc(vb)); RCQ(act_mask.alloc((u64)vb * 4));
-    RCQ(scr.alloc(scan_scratch_elems(vb))); RCQ(tots.alloc(2));
-    DBuf<u32> sketch_tmp;
+    DBuf<u64> codes_tmp, tots;
+    RCQ(codes_tmp.alloc(n)); RCQ(tots.alloc(2));
+    DBuf<u64> skb_tmp;
+    DBuf<u32> skc_tmp;
     SortArrays ck, ct;
     ck.a = codes.p; ct.a = codes_tmp.p;
-    if (sketch) { RCQ(sketch_tmp.alloc(n)); ck.c = sketch; ct.c = sketch_tmp.p; }     // the sketches travel with their records
-    if (radix_sort(s, ck, ct, n, 32, 64, job->sort_scratch, &job->sort_timing, first_hist)) return fail(100, "radix sort failed");
-    launch_active_count(s, ck.a, n, blk_active.p, act_mask.p);
-    if (exclusive_scan_u32_to_u64(s, blk_active.p, blk_off.p, vb, scr.p, tots.p)) return fail(100, "scan launch failed");
-    u64 n_active = 0;
-    HIPQ(hipMemcpyAsync(&n_active, tots.p, sizeof n_active, hipMemcpyDeviceToHost, s));
+    if (sk_b) { RCQ(skb_tmp.alloc(n)); ck.b = sk_b; ct.b = skb_tmp.p; }               // the sketches travel with their records
+    if (sk_c) { RCQ(skc_tmp.alloc(n)); ck.c = sk_c; ct.c = skc_tmp.p; }
+    // the records are a (code << 32 | position); with a b array the sort's logical key is a:b, i.e. a's bits sit 64 higher
+    const int key_lo = sk_b ? 96 : 32, key_hi = sk_b ? 128 : 64;
+    if (radix_sort(s, ck, ct, n, key_lo, key_hi, job->sort_scratch, &job->sort_timing, first_hist)) return fail(100, "radix sort failed");
+    const u64 ab = verify_blocks(n);                             // workgroups (tiles) of the candidate kernels
+    u64 totals[2] = {0, 0};                                      // slots, comparisons
+    DBuf<PairRec> slots;
+    {
+        DBuf<u32> cnt_slots, blk_slots;
+        DBuf<u64> blk_cand, slot_off, scr_a;
+        RCQ(cnt_slots.alloc(ab * 256)); RCQ(blk_slots.alloc(ab)); RCQ(blk_cand.alloc(ab));
+        RCQ(slot_off.alloc(ab)); RCQ(scr_a.alloc(scan_scratch_elems(ab)));
+        launch_candidates_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c);
+        if (exclusive_scan_u32_to_u64(s, blk_slots.p, slot_off.p, ab, scr_a.p, tots.p)) return fail(100, "scan launch failed");
+        HIPQ(hipMemsetAsync(tots.p + 1, 0, sizeof(u64), s));
+        launch_sum_u64(s, blk_cand.p, ab, tots.p + 1);
+        HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        job->stats.candidate_pairs += totals[1];
+        if (totals[0] == 0) { HIPQ(hipGetLastError()); return 0; }
+        RCQ(slots.alloc(totals[0]));
+        launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c);
+    }
+    const u64 n_slots = totals[0], jb = (n_slots + 255) / 256;
+    DBuf<u32> blk_valid;
+    DBuf<u64> pair_off, scr_j;
+    RCQ(blk_valid.alloc(jb)); RCQ(pair_off.alloc(jb)); RCQ(scr_j.alloc(scan_scratch_elems(jb)));
+    launch_judge(s, dp, job->pk.p, slots.p, n_slots, seed, blk_valid.p);
+    if (exclusive_scan_u32_to_u64(s, blk_valid.p, pair_off.p, jb, scr_j.p, tots.p)) return fail(100, "scan launch failed");
+    u64 n_new = 0;
+    HIPQ(hipMemcpyAsync(&n_new, tots.p, sizeof n_new, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
-    if (n_active == 0) return 0;
-    if (n_active >= (1ull << 32)) return fail(19, "too many run members");
-    DBuf<u32> active, cnt_recs, cnt_cand;
-    DBuf<u64> rec_off, cand_off, scr_a;
-    RCQ(active.alloc(n_active)); RCQ(cnt_recs.alloc(n_active)); RCQ(cnt_cand.alloc(n_active));
-    RCQ(rec_off.alloc(n_active)); RCQ(cand_off.alloc(n_active)); RCQ(scr_a.alloc(scan_scratch_elems(n_active)));
-    launch_active_emit(s, act_mask.p, n, blk_off.p, active.p);
-    launch_verify_count(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, cnt_recs.p, cnt_cand.p, ck.c);
-    if (exclusive_scan_u32_to_u64(s, cnt_recs.p, rec_off.p, n_active, scr_a.p, tots.p)) return fail(100, "scan launch failed");
-    if (exclusive_scan_u32_to_u64(s, cnt_cand.p, cand_off.p, n_active, scr_a.p, tots.p + 1)) return fail(100, "scan launch failed");
-    u64 totals[2] = {0, 0};
-    HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
-    HIPQ(hipStreamSynchronize(s));
-    job->stats.candidate_pairs += totals[1];
-    if (ps.n + totals[0] > ps.cap || !ps.pairs.p) {              // grow, keeping the earlier seeds' records
-        const u64 want = (ps.n + totals[0]) * 2 + (1u << 20);
+    if (ps.n + n_new > ps.cap || !ps.pairs.p) {                  // grow, keeping the earlier seeds' records
+        const u64 want = (ps.n + n_new) * 2 + (1u << 20);
         DBuf<PairRec> bigger;
         RCQ(bigger.alloc(want));
         if (ps.n) HIPQ(hipMemcpyAsync(bigger.p, ps.pairs.p, ps.n * sizeof(PairRec), hipMemcpyDeviceToDevice, s));
@@ -274,8 +284,8 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         std::swap(ps.pairs.p, bigger.p); std::swap(ps.pairs.n, bigger.n); std::swap(ps.pairs.pool, bigger.pool);
         ps.cap = want;
     }
-    if (totals[0]) launch_verify_write(s, dp, job->pk.p, ck.a, active.p, (u32)n_active, seed, rec_off.p, cnt_recs.p, ps.pairs.p + ps.n, ck.c);
-    ps.n += totals[0];
+    if (n_new) launch_slot_compact(s, slots.p, n_slots, pair_off.p, ps.pairs.p + ps.n);
+    ps.n += n_new;
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
     return 0;
