@@ -217,16 +217,29 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         sk.on = use_sketch;
         const u32 tile_recs = radix_sort_tile_records(use_sketch && dp.nseeds >= 3, use_sketch && dp.nseeds != 3);
         const u64 tiles = (NR + tile_recs - 1) / tile_recs;
-        for (int q = 0; q < dp.nseeds; q++) {
+        // With sketches (large references) the records of one seed are made, sorted and verified before the next seed's are
+        // made: all seeds at once took 16 (d + 1) bytes per representative on top of the sort's spare buffers -- 242 GB
+        // in use at once on a GRCh38-sized reference.  Without them every seed's codes come from one pass.
+        const bool per_seed = use_sketch;
+        auto make = [&](int q) -> int {
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
             cp[q] = codes[q].p; hp[q] = hists[q].p;
             if (use_sketch && dp.nseeds >= 3) { RCQ(skb[q].alloc(NR)); sk.b[q] = skb[q].p; }
             if (use_sketch && dp.nseeds != 3) { RCQ(skc[q].alloc(NR)); sk.c[q] = skc[q].p; }
+            return 0;
+        };
+        if (!per_seed) {
+            for (int q = 0; q < dp.nseeds; q++) RCQ(make(q));
+            launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs);
         }
-        launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs);
         for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
+            if (per_seed) {
+                RCQ(make(seed - 1));
+                launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, seed - 1);
+            }
             RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, sk.b[seed - 1], sk.c[seed - 1]));
             codes[seed - 1].release(); hists[seed - 1].release(); skb[seed - 1].release(); skc[seed - 1].release();
+            cp[seed - 1] = nullptr; hp[seed - 1] = nullptr; sk.b[seed - 1] = nullptr; sk.c[seed - 1] = nullptr;
         }
         st.hom_pairs = ps.n;
     }
@@ -257,8 +270,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     st.ms_sort_scatter = job->sort_timing.scatter_ms;
     st.n_sort_scatter = job->sort_timing.scatter_launches;
     st.sort_scatter_bytes = job->sort_timing.scatter_bytes;
-    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] run %.3f ms; device pool: %zu blocks, %zu hipMalloc calls so far (%.1f MB)\n", st.ms_total,
-                                      job->pool.blocks.size(), job->pool.n_malloc, job->pool.malloc_bytes / 1e6);
+    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] run %.3f ms; device pool: %zu blocks, %zu hipMalloc calls so far (%.1f MB), most in use at once %.1f MB\n",
+                                      st.ms_total, job->pool.blocks.size(), job->pool.n_malloc, job->pool.malloc_bytes / 1e6, job->pool.peak_live / 1e6);
     return 0;
 }
 

@@ -41,14 +41,23 @@ struct DevPool {
     struct Block { void *p; size_t bytes; bool free; };
     std::vector<Block> blocks;
     size_t n_malloc = 0, malloc_bytes = 0;               // since the pool was made (CORA_TRACE prints them per run)
+    size_t live_bytes = 0, peak_live = 0;                // bytes handed out now / at most
     void *get(size_t bytes)
     {
         bytes = (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
+        // smallest free block that holds the request.  A close fit (within 25 %) is the common case: the same sizes recur
+        // in every run.  A LARGE request also takes a larger block rather than growing the pool: the stages of a
+        // GRCh38-sized build ask for arrays of 12-47 GB each, and a pool that only ever adds blocks ended at 277 GB.
         int best = -1;
+        const bool any_fit = bytes >= ((size_t)256 << 20);
         for (size_t i = 0; i < blocks.size(); i++)
-            if (blocks[i].free && blocks[i].bytes >= bytes && blocks[i].bytes <= bytes + bytes / 4 + (4u << 20) &&
+            if (blocks[i].free && blocks[i].bytes >= bytes && (any_fit || blocks[i].bytes <= bytes + bytes / 4 + (4u << 20)) &&
                 (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = (int)i;
-        if (best >= 0) { blocks[best].free = false; return blocks[best].p; }
+        if (best >= 0) {
+            blocks[best].free = false;
+            live_bytes += blocks[best].bytes; if (live_bytes > peak_live) peak_live = live_bytes;
+            return blocks[best].p;
+        }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) {
             trim();                                          // give cached blocks back and retry once
@@ -56,11 +65,12 @@ struct DevPool {
         }
         blocks.push_back({p, bytes, false});
         n_malloc++; malloc_bytes += bytes;
+        live_bytes += bytes; if (live_bytes > peak_live) peak_live = live_bytes;
         return p;
     }
     void put(void *p)
     {
-        for (auto &b : blocks) if (b.p == p) { b.free = true; return; }
+        for (auto &b : blocks) if (b.p == p) { if (!b.free) live_bytes -= b.bytes; b.free = true; return; }
     }
     void trim()
     {

@@ -838,7 +838,7 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ reps, u64 n_reps,
                                                         u64 *__restrict__ out0, u64 *__restrict__ out1, u64 *__restrict__ out2,
                                                         u64 *__restrict__ out3, u32 *__restrict__ hist0, u32 *__restrict__ hist1,
-                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3, SeedSketches sk, int per_thread)
+                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3, SeedSketches sk, int per_thread, int only)
 {
     __shared__ u32 h[NS][256];
     const int tid = threadIdx.x;
@@ -861,6 +861,7 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
         for (int s = 0; s < NS; s++) { fwc[s] = seed_code_fixed<NS>(hi, tail, s, p.seed_q); rcc[s] = rc_code(fwc[s]); }
 #pragma unroll
         for (int s = 0; s < NS; s++) {
+            if (only >= 0 && s != only) continue;             // one seed per launch (large references: memory)
             const bool fwd = fwc[s] <= rcc[s];
             const u32 c = fwd ? fwc[s] : rcc[s];
             outs[s][r] = ((u64)c << 32) | g;
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
     __syncthreads();
     u32 *const hists[4] = {hist0, hist1, hist2, hist3};
 #pragma unroll
-    for (int s = 0; s < NS; s++) hists[s][(size_t)blockIdx.x * 256 + tid] = h[s][tid];
+    for (int s = 0; s < NS; s++) if (only < 0 || s == only) hists[s][(size_t)blockIdx.x * 256 + tid] = h[s][tid];
 }
 
 struct Mism { u64 hi, lo; };
@@ -1762,15 +1763,15 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
     if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
 }
 void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
-                           const SeedSketches &sk, u32 tile_records)
+                           const SeedSketches &sk, u32 tile_records, int only)
 {
     if (!n_reps) return;
     const dim3 g((unsigned)((n_reps + tile_records - 1) / tile_records));
     const int per_thread = (int)(tile_records / 256);
     switch (p.nseeds) {
-    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread); break;
-    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread); break;
-    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread); break;
+    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only); break;
+    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only); break;
+    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only); break;
     }
 }
 u64 verify_blocks(u64 n) { return (n + VT_TILE - 1) / VT_TILE; }

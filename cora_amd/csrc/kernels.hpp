@@ -97,7 +97,8 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
 // per-seed sketch arrays (k_seed_codes_all): b = two other seeds' codes (nseeds >= 3), c = one more code (nseeds 2 and 4)
 struct SeedSketches { int on; u64 *b[4]; u32 *c[4]; };
 void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
-                           const SeedSketches &sk, u32 tile_records /* radix_sort_tile_records() of the record shape */);
+                           const SeedSketches &sk, u32 tile_records /* radix_sort_tile_records() of the record shape */,
+                           int only = -1 /* >= 0: write this (0-based) seed's arrays only */);
 // Pair verification over the n code-sorted records of one seed (kernels.hip: k_candidates, k_judge, k_slot_compact).
 // candidates: one workgroup per tile of records; cnt_slots[verify_blocks(n) * 256] per thread, blk_slots / blk_cand per
 // workgroup; sk_*: the sketches, sorted with the codes, or null.  judge: slots -> pair records or none, in place, and

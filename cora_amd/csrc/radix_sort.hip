@@ -205,8 +205,9 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
             cv[r] = (li < count) ? __builtin_nontemporal_load(c_in + base + li) : 0;
         }
     }
-    u64 ov[HAS_B ? RS_IPT : 1];             // so is the other key word
-    if (HAS_B) {
+    constexpr bool PRE_B = HAS_B && THREADS == 256;     // (512-thread tiles: the 32 registers would leave one workgroup per CU)
+    u64 ov[PRE_B ? RS_IPT : 1];             // so is the other key word
+    if (PRE_B) {
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            if (li < count) stage[lpos[r]] = ov[r];
+            if (li < count) stage[lpos[r]] = PRE_B ? ov[r] : oth_in[base + li];
         }
         __syncthreads();
 #pragma unroll
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
     }
 }
 
-u32 radix_sort_tile_records(bool has_b, bool has_c) { (void)has_b; return has_c ? 512 * RS_IPT : 256 * RS_IPT; }
+u32 radix_sort_tile_records(bool has_b, bool has_c) { return (has_b || has_c) ? 512 * RS_IPT : 256 * RS_IPT; }
 
 int SortScratch::reserve(u64 n)
 {
@@ -352,7 +353,7 @@ template <bool HAS_B, bool HAS_C>
 static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
                            int shift, u32 mask, const u32 *tile_off, u32 xg)
 {
-    constexpr int T = HAS_C ? 512 : 256;
+    constexpr int T = (HAS_C || HAS_B) ? 512 : 256;
     if (HAS_B && dig_b)
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
                            out.c, n, shift, mask, tile_off, xg);
@@ -390,7 +391,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const u64 *word = dig_b ? keys.b : keys.a;
         u32 *th = scratch.tile_hist;
         if (pass == 0 && first_hist) th = first_hist;                    // the producer already counted this digit (tiles of radix_sort_tile_records())
-        else if (has_c) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th);
+        else if (has_c || has_b) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th);
         else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th);
         hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums);
         u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
