@@ -204,7 +204,25 @@ int main(int argc, char **argv)
     if (!rc) rc = cora_hip_job_set_reference_fasta(job, fa);
     cora_hip_fasta_destroy(fa);
     const double ms_load = ms_since(t_start);
-    if (!rc) rc = cora_hip_job_run(job);
+    // Every GPU of the node takes part (cora starts ONE process, cora.cpp:1586): one host thread per GPU, records exchanged
+    // peer to peer.  A reference below 256 Mbp is built on one GPU (the exchanges would cost more than they save).
+    // CORA_GPUS=n limits the GPUs used; CORA_RANKS=n forces n ranks, dealt over the GPUs in use (n > GPUs: ranks share a
+    // GPU -- the rehearsal the tests run on a one-GPU box).
+    int n_gpus = 1, ranks = 1;
+    if (!rc) rc = cora_hip_device_count(&n_gpus);
+    if (const char *e = getenv("CORA_GPUS")) { const int v = atoi(e); if (v >= 1 && v < n_gpus) n_gpus = v; }
+    unsigned long long total_bases = 0;
+    for (long long l : fai_len) total_bases += (unsigned long long)l;
+    ranks = total_bases >= 256000000ull ? n_gpus : 1;
+    if (const char *e = getenv("CORA_RANKS")) { const int v = atoi(e); if (v >= 1 && v <= 64) ranks = v; }
+    if (!rc) {
+        if (ranks > 1) {
+            std::vector<int> devs(ranks);
+            for (int r = 0; r < ranks; r++) devs[r] = r % n_gpus;
+            std::cout << "Building on " << ranks << " ranks over " << (ranks < n_gpus ? ranks : n_gpus) << " GPU(s)" << std::endl;
+            rc = cora_hip_job_run_multi(job, ranks, devs.data());
+        } else rc = cora_hip_job_run(job);
+    }
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
     const double ms_build = ms_since(t_start);
 

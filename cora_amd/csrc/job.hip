@@ -44,6 +44,7 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
     if (params->line_width < 1) return fail(51, "bad FASTA line width %d", params->line_width);
     cora_hip_job *j = new cora_hip_job();
     j->prm = *params;
+    if (hipGetDevice(&j->device) != hipSuccess) { delete j; return fail(100, "hipGetDevice failed"); }
     memset(&j->stats, 0, sizeof j->stats);
     HostGenome &hg = j->hg;
     hg.K = params->K; hg.d = params->d; hg.chr_short = params->chr_short;
@@ -63,6 +64,8 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
 extern "C" void cora_hip_job_destroy(cora_hip_job *job)
 {
     if (!job) return;
+    multi_state_free(job);
+    (void)hipSetDevice(job->device);
     shard_state_free(job);
     job->sort_scratch.release();
     job->raw.release(); job->d_gstart.release(); job->d_off.release(); job->d_len.release(); job->d_window.release();
@@ -109,6 +112,9 @@ int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_
     hg.gstart[n_contigs] = G;
     plan_windows(hg.d, hg.len, hg.window);
     job->genome_bases = bases;
+    job->ref_contigs.assign(contigs, contigs + n_contigs);
+    job->ref_W = W; job->ref_image_bytes = image_bytes;
+    multi_state_free(job);                                         // replicas of an earlier reference are stale
 
     if (adopt) {
         job->raw.release();

@@ -162,6 +162,11 @@ struct cora_hip_job {
     HBuf<int16_t> h_blen;
     int host_threads = 8;
     struct ShardState *shard = nullptr;   // multi-GPU stage state (shard.hip)
+    struct MultiState *multi = nullptr;   // the other ranks' jobs of an in-process multi-GPU run (multi.hip)
+    int device = 0;                       // HIP device the job's memory and stream live on
+    std::vector<cora_hip_contig> ref_contigs;   // what set_reference_impl was given (a multi-GPU run replicates the reference)
+    u32 ref_W = 0;
+    size_t ref_image_bytes = 0;
     int sketch_mode = -1;         // -1 = by size (job.hip: SKETCH_MIN_REPS); CORA_SKETCH=0/1 overrides
     int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
     ByteBuf exact_bytes, inexact_bytes;
@@ -250,5 +255,6 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
                    u64 *sk_b = nullptr, u32 *sk_c = nullptr /* [n] per-record sketches for k_verify's pre-filter; sorted along */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
+void multi_state_free(cora_hip_job *job);
 int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_t n_contigs, u32 W, size_t image_bytes,
                        const uint8_t *host_image, const uint8_t *dev_image, DBuf<u8> *adopt);

@@ -866,13 +866,13 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
             const u32 c = fwd ? fwc[s] : rcc[s];
             outs[s][r] = ((u64)c << 32) | g;
             atomicAdd(&h[s][c & 255u], 1u);
-            if (sk.on) {
+            if (sk.on) {                                       // (an array that is not wanted is null: the sharded flow moves b only)
                 const u32 o1 = fwd ? fwc[(s + 1) % NS] : rcc[(s + 1) % NS];
-                if (NS == 2) sk.c[s][r] = o1;
+                if (NS == 2) { if (sk.c[s]) sk.c[s][r] = o1; }
                 else {
                     const u32 o2 = fwd ? fwc[(s + 2) % NS] : rcc[(s + 2) % NS];
-                    sk.b[s][r] = ((u64)o1 << 32) | o2;
-                    if (NS == 4) sk.c[s][r] = fwd ? fwc[(s + 3) % NS] : rcc[(s + 3) % NS];
+                    if (sk.b[s]) sk.b[s][r] = ((u64)o1 << 32) | o2;
+                    if (NS == 4 && sk.c[s]) sk.c[s][r] = fwd ? fwc[(s + 3) % NS] : rcc[(s + 3) % NS];
                 }
             }
         }
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
     __syncthreads();
     u32 *const hists[4] = {hist0, hist1, hist2, hist3};
 #pragma unroll
-    for (int s = 0; s < NS; s++) if (only < 0 || s == only) hists[s][(size_t)blockIdx.x * 256 + tid] = h[s][tid];
+    for (int s = 0; s < NS; s++) if ((only < 0 || s == only) && hists[s]) hists[s][(size_t)blockIdx.x * 256 + tid] = h[s][tid];
 }
 
 struct Mism { u64 hi, lo; };
@@ -1960,4 +1960,20 @@ void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 
     q.pos_base = (u64)block_lo * 256;
     hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, q, pk, valid, block_off, rec, gpos);
 }
+}  // namespace cora
+
+// ---- element-wise combines of the in-process multi-GPU run (multi.hip): a peer's array folded into this rank's
+namespace cora {
+__global__ __launch_bounds__(256) void k_or_u32(u32 *__restrict__ acc, const u32 *__restrict__ other, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] |= other[i];
+}
+__global__ __launch_bounds__(256) void k_add_u32(u32 *__restrict__ acc, const u32 *__restrict__ other, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] += other[i];
+}
+void launch_or_u32(hipStream_t s, u32 *acc, const u32 *other, u64 n) { if (n) hipLaunchKernelGGL(k_or_u32, grid_for(n), dim3(256), 0, s, acc, other, n); }
+void launch_add_u32(hipStream_t s, u32 *acc, const u32 *other, u64 n) { if (n) hipLaunchKernelGGL(k_add_u32, grid_for(n), dim3(256), 0, s, acc, other, n); }
 }  // namespace cora

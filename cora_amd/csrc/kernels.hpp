@@ -146,3 +146,8 @@ void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, 
 void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *valid, const u64 *block_off,
                                    u32 block_lo, u32 n_blocks, u64 *rec, u32 *gpos);
 }  // namespace cora
+
+namespace cora {
+void launch_or_u32(hipStream_t s, u32 *acc, const u32 *other, u64 n);
+void launch_add_u32(hipStream_t s, u32 *acc, const u32 *other, u64 n);
+}  // namespace cora

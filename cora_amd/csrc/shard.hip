@@ -26,8 +26,9 @@ struct ShardState {
     int rank = 0, world = 1;
     u32 blk_lo = 0, blk_n = 0;
     u64 word_lo = 0, word_hi = 0;
-    DBuf<u64> send_a, recv_a;
+    DBuf<u64> send_a, recv_a, send_b, recv_b;       // b: the seed records' sketches (large references), moved like a
     DBuf<u32> send_c, recv_c;
+    bool seed_sketch = false;
     u64 n_send = 0, n_recv = 0;
     DBuf<u32> repmask_g;
     ExactLocal x;
@@ -55,12 +56,12 @@ void shard_state_free(cora_hip_job *job)
 }
 
 enum { SLOT_SEND_A = 0, SLOT_SEND_C, SLOT_RECV_A, SLOT_RECV_C, SLOT_REPMASK, SLOT_X_CLS, SLOT_X_CNT, SLOT_X_ENT, SLOT_X_DIR,
-       SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_WCOUNT, SLOT_F2, SLOT_RX_F2, SLOT_STATS, SLOT_COUNT };
+       SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_WCOUNT, SLOT_F2, SLOT_RX_F2, SLOT_STATS, SLOT_SEND_B, SLOT_RECV_B, SLOT_COUNT };
 enum { ST_KMERS = 1, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH, ST_ITEM_CUT, ST_COLLECT };
 constexpr u32 N_STATS = 8;              // inexact_nodes, dirty, big, inexact_items, hom_pairs, candidate_pairs, 2 spare
 
 // stable partition of (a[, c]) by destination rank; counts[r] = records for rank r
-static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts)
+static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts, DBuf<u64> *b2 = nullptr)
 {
     hipStream_t s = job->stream;
     for (int r = 0; r < world; r++) counts[r] = 0;
@@ -73,6 +74,16 @@ static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 
     HIPQ(hipMemsetAsync(dcnt.p, 0, 256 * sizeof(unsigned long long), s));
     launch_dest_keys(s, a.p, n, mode, (u32)world, dest.p);
     launch_count_dest(s, dest.p, n, (u32)world, dcnt.p);
+    if (b2) {                                                 // the same stable pass over (dest, b2): the same permutation
+        DBuf<u64> dest2, tdest2, tb;
+        RCQ(dest2.alloc(n)); RCQ(tdest2.alloc(n)); RCQ(tb.alloc(n));
+        HIPQ(hipMemcpyAsync(dest2.p, dest.p, n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        SortArrays k2, t2;
+        k2.a = dest2.p; k2.b = b2->p; t2.a = tdest2.p; t2.b = tb.p;
+        if (radix_sort(s, k2, t2, n, 64, 72, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+        HIPQ(hipStreamSynchronize(s));
+        if (k2.b != b2->p) std::swap(b2->p, tb.p);
+    }
     SortArrays keys, tmp;
     keys.a = dest.p; keys.b = a.p; keys.c = c ? c->p : nullptr;
     tmp.a = tdest.p; tmp.b = ta.p; tmp.c = c ? tc.p : nullptr;
@@ -162,14 +173,30 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     case ST_SEED: {
         RCQ(sh.send_a.alloc(sh.n_reps));
         sh.n_send = sh.n_reps;
-        launch_seed_codes(s, dp, job->pk.p, sh.reps.p, sh.n_reps, arg, sh.send_a.p);
+        // large references: the records carry the two following seeds' codes as a sketch (kernels.hip, k_seed_codes_all); every
+        // rank takes the same decision, from the size of the reference
+        sh.seed_sketch = dp.nseeds >= 3 && (job->sketch_mode >= 0 ? job->sketch_mode != 0 : dp.G > (1ull << 28));
+        if (sh.seed_sketch) {
+            RCQ(sh.send_b.alloc(sh.n_reps));
+            u64 *outs[4] = {nullptr, nullptr, nullptr, nullptr};
+            u32 *hists[4] = {nullptr, nullptr, nullptr, nullptr};
+            SeedSketches sk;
+            memset(&sk, 0, sizeof sk);
+            sk.on = 1;
+            outs[arg - 1] = sh.send_a.p; sk.b[arg - 1] = sh.send_b.p;
+            launch_seed_codes_all(s, dp, job->pk.p, sh.reps.p, sh.n_reps, outs, hists, sk, RS_TILE_MIN, arg - 1);
+        } else {
+            sh.send_b.release();
+            launch_seed_codes(s, dp, job->pk.p, sh.reps.p, sh.n_reps, arg, sh.send_a.p);
+        }
         HIPQ(hipStreamSynchronize(s));
-        RCQ(partition_by_dest(job, sh.send_a, nullptr, sh.n_send, 1, sh.world, counts));
+        RCQ(partition_by_dest(job, sh.send_a, nullptr, sh.n_send, 1, sh.world, counts, sh.seed_sketch ? &sh.send_b : nullptr));
         return 0;
     }
     case ST_VERIFY: {
-        if (sh.n_recv) RCQ(st_seed_verify(job, sh.recv_a, sh.n_recv, arg, sh.ps));
-        sh.recv_a.release(); sh.send_a.release();
+        if (sh.seed_sketch && sh.n_recv && !sh.recv_b.p) return fail(19, "the seed records' sketches have not been delivered");
+        if (sh.n_recv) RCQ(st_seed_verify(job, sh.recv_a, sh.n_recv, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr));
+        sh.recv_a.release(); sh.send_a.release(); sh.recv_b.release(); sh.send_b.release();
         job->stats.hom_pairs = sh.ps.n;
         return 0;
     }
@@ -296,6 +323,8 @@ static int slot_ref(ShardState &sh, const DevParams &dp, int slot, void **p, u64
     case SLOT_WCOUNT: *p = sh.wcount.p; *n = (u64)sh.bnd.size() * sh.win; *eb = 4; return 0;
     case SLOT_F2: *p = sh.f2_dev.p; *n = sh.n_f2; *eb = 1; return 0;
     case SLOT_STATS: *p = sh.stat_dev.p; *n = sh.stat_dev.p ? N_STATS : 0; *eb = 8; return 0;
+    case SLOT_SEND_B: *p = sh.send_b.p; *n = sh.send_b.p ? sh.n_send : 0; *eb = 8; return 0;
+    case SLOT_RECV_B: *p = sh.recv_b.p; *n = sh.recv_b.p ? sh.n_recv : 0; *eb = 8; return 0;
     default: return 1;
     }
 }
@@ -344,6 +373,7 @@ extern "C" int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const voi
     switch (slot) {
     case SLOT_RECV_A: RCQ(sh.recv_a.alloc(n)); sh.n_recv = n; dst = sh.recv_a.p; eb = 8; break;
     case SLOT_RECV_C: RCQ(sh.recv_c.alloc(n)); if (n != sh.n_recv) return fail(19, "RECV_C must match RECV_A"); dst = sh.recv_c.p; eb = 4; break;
+    case SLOT_RECV_B: RCQ(sh.recv_b.alloc(n)); if (n != sh.n_recv) return fail(19, "RECV_B must match RECV_A"); dst = sh.recv_b.p; eb = 8; break;
     case SLOT_REPMASK:
         if (n != job->dp.n_words) return fail(19, "bitmap size mismatch");
         RCQ(sh.repmask_g.alloc(n)); dst = sh.repmask_g.p; eb = 4; break;
@@ -380,6 +410,7 @@ extern "C" int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t
     switch (slot) {
     case SLOT_RECV_A: RCQ(sh.recv_a.alloc(n)); sh.n_recv = n; *ptr = sh.recv_a.p; break;
     case SLOT_RECV_C: if (n != sh.n_recv) return fail(19, "RECV_C must match RECV_A"); RCQ(sh.recv_c.alloc(n)); *ptr = sh.recv_c.p; break;
+    case SLOT_RECV_B: if (n != sh.n_recv) return fail(19, "RECV_B must match RECV_A"); RCQ(sh.recv_b.alloc(n)); *ptr = sh.recv_b.p; break;
     case SLOT_RX_CLS: RCQ(sh.rparts.cls.alloc(n)); sh.rparts.NNS = n; *ptr = sh.rparts.cls.p; break;
     case SLOT_RX_CNT: if (n != sh.rparts.NNS) return fail(19, "RX_CNT must match RX_CLS"); RCQ(sh.rparts.ce.alloc(n)); *ptr = sh.rparts.ce.p; break;
     case SLOT_RX_ENT: RCQ(sh.rparts.ent.alloc(n)); sh.rparts.NE = n; *ptr = sh.rparts.ent.p; break;
@@ -388,6 +419,15 @@ extern "C" int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t
     default: return fail(19, "slot %d cannot be reserved", slot);
     }
     HIPQ(hipStreamSynchronize(job->stream));
+    return 0;
+}
+
+// after a SEED stage: do the seed records of this build carry sketches (SEND_B / RECV_B move like SEND_A / RECV_A)?  The same
+// answer on every rank: it follows from the size of the reference.
+extern "C" int cora_hip_shard_seed_sketch(cora_hip_job *job, int *on)
+{
+    if (!job || !job->shard || !on) return fail(19, "bad argument");
+    *on = job->shard->seed_sketch ? 1 : 0;
     return 0;
 }
 

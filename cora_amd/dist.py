@@ -21,7 +21,7 @@ from . import hip
 
 ST_KMERS, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH, ST_ITEM_CUT, ST_COLLECT = range(1, 12)
 (SLOT_SEND_A, SLOT_SEND_C, SLOT_RECV_A, SLOT_RECV_C, SLOT_REPMASK, SLOT_X_CLS, SLOT_X_CNT, SLOT_X_ENT, SLOT_X_DIR,
- SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_WCOUNT, SLOT_F2, SLOT_RX_F2, SLOT_STATS) = range(17)
+ SLOT_RX_CLS, SLOT_RX_CNT, SLOT_RX_ENT, SLOT_RX_DIR, SLOT_WCOUNT, SLOT_F2, SLOT_RX_F2, SLOT_STATS, SLOT_SEND_B, SLOT_RECV_B) = range(19)
 
 _DTYPE = {8: torch.int64, 4: torch.int32, 1: torch.uint8}
 _TYPESTR = {8: "<i8", 4: "<i4", 1: "|u1"}
@@ -175,7 +175,13 @@ class ShardedJob:
         # inexact: seed records to the owner of their code hash, verification there
         self._stage(ST_REPS)
         for seed in range(1, self.job.d + 2):
-            self._route([(SLOT_SEND_A, SLOT_RECV_A)], self._stage(ST_SEED, seed))
+            counts = self._stage(ST_SEED, seed)
+            pairs = [(SLOT_SEND_A, SLOT_RECV_A)]
+            on = C.c_int()
+            hip._check(lib.cora_hip_shard_seed_sketch(h, C.byref(on)))
+            if on.value:                                  # large references: the records' sketches travel along (same answer on every rank)
+                pairs.append((SLOT_SEND_B, SLOT_RECV_B))
+            self._route(pairs, counts)
             self._stage(ST_VERIFY, seed)
         # lists are finished by the owner of their source position; intervals are cut where a position holds no list
         self._stage(ST_ITEMS)

@@ -20,10 +20,10 @@ BIN_DIR = os.path.join(_HERE, "bin")
 
 EXPORTS = [
     "cora_hip_init", "cora_hip_shutdown", "cora_hip_last_error", "cora_hip_job_create", "cora_hip_job_destroy",
-    "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_tables", "cora_hip_job_stats",
+    "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_run_multi", "cora_hip_device_count", "cora_hip_job_tables", "cora_hip_job_stats",
     "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers",
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
-    "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
+    "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_seed_sketch", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
     "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
     "cora_hip_tables_export", "cora_hip_tables_lookup_equiv", "cora_hip_tables_destroy",
     "cora_hip_fasta_scan", "cora_hip_fasta_get_info", "cora_hip_fasta_fai_text", "cora_hip_fasta_contig",
@@ -120,6 +120,8 @@ def lib():
         L.cora_hip_job_destroy.restype = None
         L.cora_hip_job_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Contig), C.c_int32]
         L.cora_hip_job_run.argtypes = [C.c_void_p]
+        L.cora_hip_job_run_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.cora_hip_device_count.argtypes = [C.POINTER(C.c_int)]
         L.cora_hip_job_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.cora_hip_job_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.cora_hip_radix_sort.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_int, C.c_int]
@@ -136,6 +138,7 @@ def lib():
         L.cora_hip_shard_slot_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
         L.cora_hip_shard_slot_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cora_hip_shard_slot_reserve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+        L.cora_hip_shard_seed_sketch.argtypes = [C.c_void_p, C.c_void_p]
         L.cora_hip_shard_get_first_singleton.argtypes = [C.c_void_p, C.c_void_p]
         L.cora_hip_shard_set_first_singleton.argtypes = [C.c_void_p, C.c_uint64]
         L.cora_hip_tables_load.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint64,
@@ -327,6 +330,11 @@ class Job:
 
     def run(self):
         _check(lib().cora_hip_job_run(self._h))
+
+    def run_multi(self, world, devices=None):
+        """One build over `world` ranks of THIS process (cora_hip_job_run_multi); devices may repeat (ranks sharing a GPU)."""
+        arr = (C.c_int * world)(*devices) if devices is not None else None
+        _check(lib().cora_hip_job_run_multi(self._h, world, arr))
 
     def tables(self):
         ex, inx = C.c_void_p(), C.c_void_p()

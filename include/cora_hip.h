@@ -115,7 +115,17 @@ enum cora_hip_shard_stage_id { CORA_ST_KMERS = 1, CORA_ST_EXACT, CORA_ST_PARTS, 
 enum cora_hip_shard_slot_id { CORA_SLOT_SEND_A = 0, CORA_SLOT_SEND_C, CORA_SLOT_RECV_A, CORA_SLOT_RECV_C, CORA_SLOT_REPMASK,
                               CORA_SLOT_X_CLS, CORA_SLOT_X_CNT, CORA_SLOT_X_ENT, CORA_SLOT_X_DIR,
                               CORA_SLOT_RX_CLS, CORA_SLOT_RX_CNT, CORA_SLOT_RX_ENT, CORA_SLOT_RX_DIR,
-                              CORA_SLOT_WCOUNT, CORA_SLOT_F2, CORA_SLOT_RX_F2, CORA_SLOT_STATS };
+                              CORA_SLOT_WCOUNT, CORA_SLOT_F2, CORA_SLOT_RX_F2, CORA_SLOT_STATS,
+                              CORA_SLOT_SEND_B, CORA_SLOT_RECV_B /* the seed records' sketches (large references): moved like SEND_A / RECV_A when present */ };
+/* The same flow from ONE process: `world` ranks, one host thread each, rank r on HIP device devices[r] (NULL = rank r on
+ * device r modulo the device count; devices may repeat -- several ranks on one GPU, the rehearsal the tests run).
+ * devices[0] must be the device the job was created on.  The other ranks' replicas of the reference are copied from
+ * the job's own (device to device) and kept for later calls; records move between the ranks by peer-to-peer copies over
+ * xGMI (hipMemcpyPeerAsync, every receiver pulling from every sender).  On return the job holds both tables and the
+ * whole-job counts, exactly as after cora_hip_job_run -- byte for byte the same tables.  This is what the drop-in
+ * executable runs when it finds more than one GPU (cora.cpp:1586 starts one process, whatever the machine holds). */
+int cora_hip_job_run_multi(cora_hip_job *job, int world, const int *devices);
+int cora_hip_device_count(int *n);
 int cora_hip_shard_begin(cora_hip_job *job, int rank, int world);
 /* Runs one stage; counts[world] (may be NULL) receives how many records of the SEND slots go to each rank. */
 int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint64_t *counts);
@@ -127,6 +137,8 @@ int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const void *src_devi
 /* Sizes a receive slot (RECV_*, RX_*) for n_elems and returns its device address: the caller's collective then delivers
  * straight into the library's memory instead of into a tensor that slot_import would copy. */
 int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t n_elems, void **ptr);
+/* After a SEED stage: 1 if the seed records carry sketches, i.e. SEND_B / RECV_B must be moved like SEND_A / RECV_A (same answer on every rank). */
+int cora_hip_shard_seed_sketch(cora_hip_job *job, int *on);
 int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
 int cora_hip_shard_set_first_singleton(cora_hip_job *job, uint64_t key);
 

@@ -34,6 +34,8 @@ def test_sharded_ranks_over_gloo_equal_reference(world, tmp_path):
     script = os.path.join(helpers.ROOT, "tests", "support", "sharded_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world), CORA_TEST_CASES=",".join(CASES),
                CORA_TEST_OUT=str(tmp_path))
+    if world == 3:
+        env["CORA_SKETCH"] = "1"       # the seed records carry sketches (what a large reference switches on): one more slot to move
     procs = [subprocess.Popen([sys.executable, script, str(r), str(world)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     outs = [p.communicate(timeout=280)[0] for p in procs]
@@ -60,3 +62,60 @@ def test_rccl_collectives_single_rank():
         c, want = helpers.golden_case(name)
         assert helpers.read(os.path.join(env["CORA_TEST_OUT"], name + ".Exact")) == helpers.read(os.path.join(want, "Exact")), name
         assert helpers.read(os.path.join(env["CORA_TEST_OUT"], name + ".Inexact")) == helpers.read(os.path.join(want, "Inexact")), name
+
+
+# ------------------------------------------------------------------ the same flow inside ONE process (cora_hip_job_run_multi)
+@pytest.mark.parametrize("world,sketch", [(1, None), (2, None), (3, "1"), (8, None), (8, "1")])
+def test_in_process_ranks_equal_reference(world, sketch, monkeypatch):
+    """One host thread per rank, records pulled rank to rank by device copies: the flow the executable runs on a node with
+    several GPUs, rehearsed with every rank on the one GPU.  Same bytes as the reference, same whole-job counts as the
+    single-GPU run, on two calls in a row (the ranks' replicas are kept between calls)."""
+    hip.init(0)
+    if sketch:
+        monkeypatch.setenv("CORA_SKETCH", sketch)      # sketches travel with the seed records, as on a large reference
+    for name in CASES:
+        c, want = helpers.golden_case(name)
+        job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
+        job.set_reference_file(helpers.input_path(c["input"]))
+        job.run()
+        ref = job.stats()
+        for _ in range(2):
+            job.run_multi(world, [0] * world)
+            e, en, i, inn = job.tables()
+            assert e == helpers.read(os.path.join(want, "Exact")) and i == helpers.read(os.path.join(want, "Inexact")), (name, world)
+            assert (en, inn) == (c["exact_nodes"], c["inexact_nodes"])
+            st = job.stats()
+            for k in ("kmers", "representatives", "exact_classes", "hom_pairs", "inexact_items", "inexact_nodes", "exact_nodes", "candidate_pairs"):
+                assert st[k] == ref[k], (name, world, k)
+        job.close()
+
+
+def test_in_process_ranks_refuse_bad_devices():
+    hip.init(0)
+    c, _ = helpers.golden_case("q_k50_d2")
+    job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]))
+    job.set_reference_file(helpers.input_path(c["input"]))
+    with pytest.raises(hip.CoraHipError):
+        job.run_multi(2, [0, 99])
+    with pytest.raises(hip.CoraHipError):
+        job.run_multi(0)
+    job.run_multi(2, [0, 0])                          # and the job is still usable
+    job.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_executable_builds_with_several_ranks(ranks, tmp_path):
+    """CORA_RANKS forces the executable's multi-GPU flow (it would pick it by itself for a reference above 256 Mbp on a
+    node with several GPUs): same four files."""
+    for name in ("syn_k50_d2_p10t8", "multi_k50_d2_L"):
+        c, want = helpers.golden_case(name)
+        exe = os.path.join(hip.BIN_DIR, "homTable_setup_L" if c["L"] else "homTable_setup")
+        ex, inx = str(tmp_path / (name + ".E")), str(tmp_path / (name + ".I"))
+        r = subprocess.run([exe, helpers.input_path(c["input"]), str(c["K"]), helpers.split_path("phys", c["p"]), ex, inx,
+                            helpers.split_path("par", c["t"]), "BOTH", str(c["d"]), "FULL"], env=dict(os.environ, CORA_RANKS=str(ranks)),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert "Building on %d ranks" % ranks in r.stdout
+        assert helpers.read(ex) == helpers.read(os.path.join(want, "Exact")) and helpers.read(inx) == helpers.read(os.path.join(want, "Inexact"))
+        assert helpers.read(ex + ".itemCount") == helpers.read(os.path.join(want, "Exact.itemCount"))
+        assert helpers.read(inx + ".itemCount") == helpers.read(os.path.join(want, "Inexact.itemCount"))
