@@ -262,6 +262,8 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
         job->stats.candidate_pairs += totals[1];
+        job->stats.verify_slots += totals[0];
+        if (sk_b || sk_c) job->stats.seed_sketch = 1;
         if (totals[0] == 0) { HIPQ(hipGetLastError()); return 0; }
         RCQ(slots.alloc(totals[0]));
         launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c);

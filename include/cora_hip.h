@@ -67,6 +67,8 @@ typedef struct cora_hip_stats {
     uint64_t sort_scatter_bytes;  /* algorithmic bytes those launches moved (read + write of every record) */
     uint64_t hash_mixed_runs;     /* equal-hash runs that held different K-mers and were re-ordered by key */
     uint64_t full_key_fallback;   /* 1 if the exact stage had to redo its sort on the full 128-bit keys */
+    uint64_t seed_sketch;         /* 1 if the seed records carried the other seeds' codes through their sorts (large references) */
+    uint64_t verify_slots;        /* partners the sorted records could not dismiss: K-mer pairs read from the genome, all seeds */
 } cora_hip_stats;
 
 typedef struct cora_hip_job cora_hip_job;   /* opaque */

@@ -200,12 +200,13 @@ INPUTS = {
     "syn": inp_syn, "pal": inp_pal, "q": inp_q, "q4a": lambda: inp_q4(50), "q4b": lambda: inp_q4(51),
     "lowcx": inp_lowcx, "multi": inp_multi, "fam": inp_fam,
     "ecoli_like": lambda: synth.workload_ecoli_like(2024),
-    "chr20_like": lambda: synth.workload_chr20_like(20, 64_000_000),     # bench.py's N=1 workload (configs[1])
+    "chr20_like": lambda: synth.workload_chr20_like(20, 64_000_000),     # round 1's bench workload (configs[1])
+    "grch38_like_s002": lambda: synth.workload_grch38_like(38, 0.002),   # bench.py's workload (configs[2]) scaled to 6.2 Mbp: 25 contigs
 }
 # inputs too big to commit are rebuilt from the recipe by the tests (sha256 pinned)
-RECIPE_ONLY = {"ecoli_like", "chr20_like"}
+RECIPE_ONLY = {"ecoli_like", "chr20_like", "grch38_like_s002"}
 # cases whose tables are too big to commit: only their sha256 and sizes are pinned
-HASH_ONLY = {"chr20_like_k50_d2", "chr20_like_k50_d3"}
+HASH_ONLY = {"chr20_like_k50_d2", "chr20_like_k50_d3", "grch38_like_s002_k50_d2", "grch38_like_s002_k64_d3"}
 
 #        case name        input   K   d  p   t  L
 CASES = [
@@ -232,6 +233,11 @@ CASES = [
     ("chr20_like_k50_d2", "chr20_like", 50, 2, 1, 8, 0),
     # d = 3 on a contig longer than 50 Mbp: the window-by-window compaction (HTS:1467-1581), with cora's default -p 10 -t 8
     ("chr20_like_k50_d3", "chr20_like", 50, 3, 10, 8, 0),
+    # configs[3] as SURVEY.md section 0 reads it: -H 3 -K 64 and -t 24 (LPT_4.dat line 24)
+    ("syn_k64_d3_p10t24", "syn",  64, 3, 10, 24, 0),
+    # the bench generator at 1/500 of its size (25 contigs, N runs, capped repeat families, soft-masked copies), cora's defaults
+    ("grch38_like_s002_k50_d2", "grch38_like_s002", 50, 2, 10, 8, 0),
+    ("grch38_like_s002_k64_d3", "grch38_like_s002", 64, 3, 10, 24, 0),
 ]
 
 
@@ -277,13 +283,13 @@ def main():
             dst = synth.ensure_dir(os.path.join(HERE, "cases", name))
             for fn in ("Exact", "Exact.itemCount", "Inexact", "Inexact.itemCount"):
                 shutil.copy(os.path.join(out, fn), os.path.join(dst, fn))
-        manifest["cases"][name] = {
+        manifest["cases"][name] = dict(manifest["cases"].get(name, {}), **{
             "input": inp, "K": K, "d": d, "p": p, "t": t, "L": L,
             "exact_nodes": int(open(ex + ".itemCount").read()),
             "inexact_nodes": int(open(inx + ".itemCount").read()),
             "exact_sha256": sha256(ex), "inexact_sha256": sha256(inx),
             "exact_bytes": os.path.getsize(ex), "inexact_bytes": os.path.getsize(inx), "hash_only": name in HASH_ONLY,
-        }
+        })
         print("%-22s exact %6d nodes %8d B   inexact %7d nodes %9d B" % (
             name, manifest["cases"][name]["exact_nodes"], os.path.getsize(ex),
             manifest["cases"][name]["inexact_nodes"], os.path.getsize(inx)), flush=True)

@@ -1,0 +1,126 @@
+"""BASELINE.json's large configurations on the GPU: configs[2] (GRCh38-sized, d = 2), configs[3] (-H 3 -K 64, -t 24) and
+configs[4] (repeat-rich).  No oracle reaches these sizes, so every table is checked record by record against the bases by
+oracle/table_check (pinned on the real reference's own tables by tests/test_table_check.py), builds are repeated for
+identical bytes, and each configuration has a small sibling that IS compared byte for byte: with the real reference
+(tests/golden: syn_k64_d3_p10t24, grch38_like_s002_*) or with the oracle (the repeat-rich generator at 3 Mbp)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from cora_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+TABLE_CHECK = os.path.join(helpers.ORACLE_DIR, "table_check")
+
+
+def _fai(path, names, geom, width=60):
+    with open(path + ".fai", "w") as f:
+        for name, (off, n) in zip(names, geom):
+            f.write("%s\t%d\t%d\t%d\t%d\n" % (name, n, off, width, width + 1))
+
+
+def _build_and_check(contigs, K, d, p, t, tmp_path, repeat=True, L=False):
+    names = [n for n, _ in contigs]
+    image, W, geom = synth.fasta_image(contigs, 60)
+    del contigs
+    job = hip.Job(K, d, helpers.split_path("phys", p), helpers.split_path("par", t), L)
+    job.set_reference(image, W, geom)
+    job.run()
+    e, en, x, xn = job.tables()
+    st = job.stats()
+    if repeat:                                           # a second build of the same job: the same bytes
+        job.run()
+        e2, en2, x2, xn2 = job.tables()
+        assert hashlib.sha256(e2).digest() == hashlib.sha256(e).digest() and hashlib.sha256(x2).digest() == hashlib.sha256(x).digest()
+        del e2, x2
+    job.close()
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        f.write(memoryview(image))
+    _fai(fa, names, geom)
+    ep, xp = str(tmp_path / "Exact"), str(tmp_path / "Inexact")
+    for path, b, n in ((ep, e, en), (xp, x, xn)):
+        with open(path, "wb") as f:
+            f.write(b)
+        with open(path + ".itemCount", "w") as f:
+            f.write("%d\n" % n)
+    del e, x, image
+    r = subprocess.run([TABLE_CHECK, fa, str(K), str(d), ep, xp] + (["L"] if L else []), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    for path in (fa, ep, xp):
+        os.remove(path)
+    assert r.returncode == 0, r.stdout[-2000:]
+    return st, r.stdout
+
+
+def test_config2_grch38_sized_reference(tmp_path):
+    """3.09 Gbp in 25 contigs (bench.py's workload): the 48-bit hash regime of the exact sort (above 2^27 records), the sketches
+    switched on by the size itself (not by CORA_SKETCH), per-seed record generation."""
+    assert "CORA_SKETCH" not in os.environ and "CORA_HASH_BITS" not in os.environ
+    hip.init(0)
+    st, out = _build_and_check(synth.workload_grch38_like(38, 1.0), 50, 2, 10, 8, tmp_path)
+    assert st["kmers"] > 2_900_000_000 and st["representatives"] > (1 << 30)
+    assert st["seed_sketch"] == 1 and st["full_key_fallback"] == 0 and st["hash_mixed_runs"] > 0
+    assert st["verify_slots"] < st["candidate_pairs"] // 10          # the sketches dismissed the chance partners
+    assert st["hom_pairs"] > 100_000_000 and st["inexact_nodes"] > 10_000_000
+
+
+def test_config3_k64_d3_gbp(tmp_path):
+    """-H 3 -K 64 with -t 24 on 1.08 Gbp (the same generator at scale 0.35): d = 3 compacts contigs above 50 Mbp window by
+    window (HTS:2852-2856, finish.cpp plan_windows) -- nine such contigs here; four seeds, sketches of twelve bytes."""
+    hip.init(0)
+    contigs = synth.workload_grch38_like(38, 0.35)
+    assert sum(len(s) > 50_000_000 for _, s in contigs) >= 8
+    st, out = _build_and_check(contigs, 64, 3, 10, 24, tmp_path, repeat=False)
+    assert st["kmers"] > 1_000_000_000 and st["seed_sketch"] == 1 and st["hom_pairs"] > 10_000_000
+
+
+def _repeat_rich(seed, total, fams, tandem):
+    contigs = synth.genome_with_families(seed, total, fams, name="rr")
+    g = contigs[0][1]
+    a0, a1 = total // 3, 2 * total // 3
+    g[a0:a0 + tandem] = np.resize(np.frombuffer(b"AT", dtype=np.uint8), tandem)
+    g[a1:a1 + tandem] = ord("A")
+    return contigs
+
+
+def test_config4_repeat_rich_100m(tmp_path):
+    """Families of 10^4 and 3 x 10^4 copies (at 10 % and 15 % divergence, which keeps the pair output bounded: pairs grow
+    with copies^2 x P(<= 2 mismatches in 50)), hundreds of copies at 1-3 %, and 1 Mbp each of (AT)n and (A)n: equal-code
+    runs of thousands of records for the candidate walk, exact classes of 10^6 entries."""
+    hip.init(0)
+    fams = [(300, 10_000, 0.10, 3), (150, 30_000, 0.15, 3), (600, 300, 0.03, 3), (300, 900, 0.02, 2), (1200, 40, 0.01, 2)]
+    st, out = _build_and_check(_repeat_rich(5, 100_000_000, fams, 1_000_000), 50, 2, 10, 8, tmp_path)
+    assert st["candidate_pairs"] > 1_000_000_000 and st["hom_pairs"] > 10_000_000 and st["big_nodes"] > 1000
+
+
+@pytest.mark.parametrize("sketch", ["0", "1"])
+def test_config4_repeat_rich_small_equals_oracle(sketch, tmp_path, monkeypatch):
+    """The same recipe at a size the oracle can do: byte for byte, with and without sketches (runs of 1 500 records are
+    longer than the candidate kernel's LDS window, so the walk continues in global memory)."""
+    monkeypatch.setenv("CORA_SKETCH", sketch)
+    hip.init(0)
+    fams = [(200, 1500, 0.10, 3), (120, 2500, 0.15, 3), (300, 60, 0.03, 3), (150, 90, 0.02, 2)]
+    contigs = _repeat_rich(6, 3_000_000, fams, 20_000)
+    fa = str(tmp_path / "rr.fa")
+    synth.write_fasta(fa, contigs, 60)
+    phys, par = helpers.split_path("phys", 10), helpers.split_path("par", 8)
+    oex, oinx = helpers.run_oracle(fa, 50, 2, phys, par, str(tmp_path / "oracle"))
+    e, en, i, inn, st = hip.build_tables(fa, 50, 2, phys, par)
+    assert e == helpers.read(oex) and i == helpers.read(oinx)
+    assert st["seed_sketch"] == int(sketch)
+
+
+@pytest.mark.parametrize("name", ["grch38_like_s002_k50_d2", "grch38_like_s002_k64_d3"])
+def test_bench_generator_scaled_down_matches_reference_hash(name):
+    """bench.py's generator at 1/500 of its size (25 contigs, N runs, soft-masked capped families): the real reference's
+    tables for it are pinned by sha256 (tests/golden/make_golden.py; cora's defaults -p 10 -t 8, and -t 24 for d = 3)."""
+    hip.init(0)
+    c = helpers.MANIFEST["cases"][name]
+    e, en, i, inn, st = hip.build_tables(helpers.input_path(c["input"]), c["K"], c["d"], helpers.split_path("phys", c["p"]),
+                                         helpers.split_path("par", c["t"]))
+    assert (en, inn) == (c["exact_nodes"], c["inexact_nodes"])
+    assert hashlib.sha256(e).hexdigest() == c["exact_sha256"] and hashlib.sha256(i).hexdigest() == c["inexact_sha256"]
