@@ -69,12 +69,14 @@ void plan_windows(int d, const std::vector<uint32_t> &len, std::vector<uint32_t>
     }
 }
 
-void ByteBuf::reserve_uninit(size_t c)
+bool ByteBuf::reserve_uninit(size_t c)
 {
-    if (c <= cap) return;
+    if (c <= cap && p) return true;
     free(p);
     p = (uint8_t *)malloc(c ? c : 1);
     cap = p ? c : 0;
+    if (!p) n = 0;
+    return p != nullptr;
 }
 ByteBuf::~ByteBuf() { free(p); }
 
@@ -137,13 +139,13 @@ void emit_item(Writer &w, const HostGenome &g, int d, uint32_t tgt, uint32_t dir
 // F2 (HTS:1353-1432): per source position with a surviving item: chr,pos { dir chr pos off.. blockLen }* 0xFF,
 // items by decreasing block length through std::sort (HTS:1368; unstable above 16 items, which is why the
 // very same library routine is applied to the very same pre-order here).
-static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResult &r, const View<uint64_t> &packed,
+static bool serialize_inexact_range(const HostGenome &g, const InexactDeviceResult &r, const View<uint64_t> &packed,
                                     size_t node_begin, size_t node_end, ByteBuf &out, FinishStats &st, size_t *marks)
 {
     // marks[nd - node_begin] = offset in `out` where list nd's bytes start (lists are written in order)
     const int cw = g.chr_short ? 2 : 1;
     const size_t n_items = (size_t)r.node_start[node_end] - r.node_start[node_begin];
-    out.reserve_uninit(n_items * (size_t)(1 + cw + 4 + g.d + 2) + (node_end - node_begin) * (size_t)(cw + 5) + 16);
+    if (!out.reserve_uninit(n_items * (size_t)(1 + cw + 4 + g.d + 2) + (node_end - node_begin) * (size_t)(cw + 5) + 16)) return false;
     Writer w{out.p, cw};
     st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
     const size_t n_nodes = node_end;
@@ -262,16 +264,17 @@ static void serialize_inexact_range(const HostGenome &g, const InexactDeviceResu
         i = j;
     }
     out.n = (size_t)(w.at - out.p);
+    return true;
 }
 
-void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
+bool serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
                        ByteBuf &out, FinishStats &st, int n_threads, std::vector<size_t> *marks)
 {
     if (marks) marks->assign(r.node_start.empty() ? 1 : r.node_start.size(), 0);
     const size_t n_nodes = r.node_start.empty() ? 0 : r.node_start.size() - 1;
     st.inexact_nodes = st.dirty_nodes = st.big_nodes = 0;
     out.n = 0;
-    if (n_nodes == 0) return;
+    if (n_nodes == 0) return true;
     auto src_of = [&](size_t nd) { return (uint32_t)(r.key[r.node_start[nd]] >> 32); };
     // a thread's range must start where a run of consecutive source positions starts (runs never
     // interact: HTS:1212 stops at the first position without a list)
@@ -297,17 +300,19 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
     std::vector<ByteBuf> bufs(parts);
     std::vector<FinishStats> sts(parts);
     std::vector<std::thread> th;
+    std::vector<char> ok(parts, 1);
     for (size_t k = 1; k < parts; k++)
-        th.emplace_back([&, k]() { serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k], marks ? marks->data() + cut[k] : nullptr); });
-    serialize_inexact_range(g, r, packed, cut[0], cut[1], bufs[0], sts[0], marks ? marks->data() + cut[0] : nullptr);
+        th.emplace_back([&, k]() { ok[k] = serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k], marks ? marks->data() + cut[k] : nullptr); });
+    ok[0] = serialize_inexact_range(g, r, packed, cut[0], cut[1], bufs[0], sts[0], marks ? marks->data() + cut[0] : nullptr);
     for (auto &x : th) x.join();
+    for (size_t k = 0; k < parts; k++) if (!ok[k]) return false;
     std::vector<size_t> off(parts + 1, 0);
     for (size_t k = 0; k < parts; k++) {
         off[k + 1] = off[k] + bufs[k].size();
         if (marks) for (size_t nd = cut[k]; nd < cut[k + 1]; nd++) (*marks)[nd] += off[k];
         st.inexact_nodes += sts[k].inexact_nodes; st.dirty_nodes += sts[k].dirty_nodes; st.big_nodes += sts[k].big_nodes;
     }
-    out.reserve_uninit(off[parts] + 16);
+    if (!out.reserve_uninit(off[parts] + 16)) return false;
     out.n = off[parts];
     th.clear();
     for (size_t k = 1; k < parts; k++)
@@ -315,21 +320,22 @@ void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
     if (bufs[0].size()) memcpy(out.p, bufs[0].data(), bufs[0].size());
     for (auto &x : th) x.join();
     if (marks) (*marks)[n_nodes] = off[parts];
+    return true;
 }
 
 // The device wrote the bytes of its lists back to back (`stream`); the host lists (in list order, each with the
 // stream offset its bytes belong at) are finished here and spliced in.
-void assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
+bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
                       View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads)
 {
     ByteBuf hb;
     std::vector<size_t> marks;
     FinishStats hst;
-    if (hnodes.size()) serialize_inexact(g, host_items, packed, hb, hst, n_threads, &marks);
+    if (hnodes.size() && !serialize_inexact(g, host_items, packed, hb, hst, n_threads, &marks)) return false;
     st.inexact_nodes = device_nodes + hst.inexact_nodes;
     st.dirty_nodes = hst.dirty_nodes; st.big_nodes = hst.big_nodes;
     const size_t total = stream.size() + hb.size();
-    out.reserve_uninit(total + 16);
+    if (!out.reserve_uninit(total + 16)) return false;
     out.n = total;
     struct Piece { const uint8_t *src; size_t dst, n; };
     std::vector<Piece> pieces;
@@ -352,6 +358,7 @@ void assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> 
     for (int t = 1; t < T; t++) th.emplace_back(work, t);
     work(0);
     for (auto &x : th) x.join();
+    return true;
 }
 
 }  // namespace cora

@@ -56,7 +56,7 @@ struct InexactDeviceResult {           // directed items sorted by (source, targ
 struct ByteBuf {
     uint8_t *p = nullptr;
     size_t n = 0, cap = 0;
-    void reserve_uninit(size_t c);
+    bool reserve_uninit(size_t c);       // false: the host is out of memory (the buffer is then empty, p == nullptr)
     const uint8_t *data() const { return p; }
     size_t size() const { return n; }
     ~ByteBuf();
@@ -69,10 +69,11 @@ struct FinishStats { uint64_t exact_nodes = 0, inexact_nodes = 0, dirty_nodes = 
 
 // packed: the 2-bit genome (needed only when a list has tied targets); may be empty if none has.
 // n_threads host threads each serialise a contiguous range of source positions.
-void serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
+// Both return false when a host buffer could not be allocated (nothing is written through a null pointer).
+bool serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
                        ByteBuf &out, FinishStats &st, int n_threads, std::vector<size_t> *marks = nullptr);
 // Splices the host-finished lists into the byte stream the device wrote (stages.hip, st_items_finish).
-void assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
+bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
                       View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads);
 
 }  // namespace cora

@@ -291,7 +291,7 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     }
     case ST_COLLECT: {                  // rank 0: the table is the ranks' byte ranges in rank order; counts are the sums
         cora_hip_stats &st = job->stats;
-        job->inexact_bytes.reserve_uninit(sh.n_f2_all + 16);
+        if (!job->inexact_bytes.reserve_uninit(sh.n_f2_all + 16)) return fail(101, "host allocation of %llu bytes for <Inexact> failed", (unsigned long long)sh.n_f2_all + 16);
         if (sh.n_f2_all) HIPQ(hipMemcpyAsync(job->inexact_bytes.p, sh.f2_all.p, sh.n_f2_all, hipMemcpyDeviceToHost, s));
         u64 hs[N_STATS] = {0};
         if (sh.stat_dev.p) HIPQ(hipMemcpyAsync(hs, sh.stat_dev.p, sizeof hs, hipMemcpyDeviceToHost, s));

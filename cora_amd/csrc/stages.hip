@@ -195,13 +195,13 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
         RCQ(read_counters(job, h));
         HIPQ(hipGetLastError());
         const auto h0 = std::chrono::steady_clock::now();
-        job->exact_bytes.reserve_uninit(total + 16);
+        if (!job->exact_bytes.reserve_uninit(total + 16)) return fail(101, "host allocation of %llu bytes for <Exact> failed", (unsigned long long)total + 16);
         if (total) memcpy(job->exact_bytes.p, bytes.p, total);
         job->exact_bytes.n = total;
         fst.exact_nodes = h.emitted_exact;
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     } else {
-        job->exact_bytes.reserve_uninit(16);
+        if (!job->exact_bytes.reserve_uninit(16)) return fail(101, "host allocation failed");
         job->exact_bytes.n = 0;
         fst.exact_nodes = 0;
     }
@@ -397,7 +397,8 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
     HIPQ(hipEventRecord(job->ev[4], s));
     HIPQ(hipStreamSynchronize(s));
     const auto h0 = std::chrono::steady_clock::now();
-    assemble_inexact(job->hg, stream_host, hnodes_host, ir, packed_host, device_nodes, job->inexact_bytes, fst, job->host_threads);
+    if (!assemble_inexact(job->hg, stream_host, hnodes_host, ir, packed_host, device_nodes, job->inexact_bytes, fst, job->host_threads))
+        return fail(101, "host allocation for the %zu bytes of <Inexact> failed", stream_host.size());
     fst.big_nodes = big_nodes;                           // lists above 16 items, counted on the device (most never reach the host)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     host_ms += ms;
