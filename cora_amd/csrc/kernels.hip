@@ -941,26 +941,38 @@ __device__ __forceinline__ u32 judge(const DevParams &p, Mism m, int seed, u32 d
 // (source, target) and lists with tied targets are finished in the reference's discovery order, recomputed per item.
 constexpr int VT_PER = 8;
 constexpr int VT_TILE = 256 * VT_PER;        // records per workgroup
-constexpr int VT_HALO = 512;                 // records before the tile kept in LDS as well
+constexpr int VT_HALO = 256;                 // records before the tile kept in LDS as well
+// The counting pass keeps what it finds: up to VT_QUOTA slots per tile, appended to a list in LDS (as tile-local indices,
+// each with its thread and its rank among that thread's slots, so that its final place -- thread prefix + rank -- does not
+// depend on the order of the appends) and written to the tile's quota of a staging array.  Only the tiles that do not fit
+// -- dense repeat families, palindromic codes, runs that leave LDS -- are walked a second time by the WRITE pass.
+constexpr int VT_QUOTA = 192;
 constexpr u32 SLOT_NONE = 0xFFFFFFFFu;
 enum { SLOT_PLAIN = 0, SLOT_PAL_FWD0, SLOT_PAL_FWD1, SLOT_PAL_REV0, SLOT_PAL_REV1, SLOT_PAL_SELF };
 
 template <bool WRITE, bool SKB, bool SKC>
 __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__restrict__ codes, u64 n, u32 *__restrict__ cnt_slots /* [blocks * 256] */,
                                                     u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
-                                                    PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c)
+                                                    PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c,
+                                                    u64 *__restrict__ staged /* [blocks * VT_QUOTA] */, u8 *__restrict__ blk_staged)
 {
     __shared__ u64 s_key[VT_TILE + VT_HALO];
     __shared__ u64 s_b[SKB ? VT_TILE + VT_HALO : 1];
     __shared__ u32 s_c[SKC ? VT_TILE + VT_HALO : 1];
+    __shared__ u32 s_val[WRITE ? 1 : VT_QUOTA];      // kept slots: (LDS slot of k-mer 1) << 16 | LDS slot of k-mer 2
+    __shared__ uint16_t s_own[WRITE ? 1 : VT_QUOTA];      // ... thread << 8 | rank among the thread's slots
+    __shared__ u32 s_pre[WRITE ? 1 : 256];           // slots of the threads before each thread
+    __shared__ u32 s_n;
     __shared__ u32 l4[4];
     __shared__ u64 c4[4];
     const int tid = threadIdx.x;
     const u64 base = (u64)blockIdx.x * VT_TILE;
     u64 at = 0;
     u32 mine = 1;
+    bool spill = false;                                      // counting pass: this thread's slots cannot all be kept
+    if (!WRITE && tid == 0) s_n = 0;                         // (published by the barrier behind the tile loads)
     if (WRITE) {
-        if (blk_slots[blockIdx.x] == 0) return;              // the counting pass found nothing worth a look in this tile (uniform)
+        if (blk_slots[blockIdx.x] == 0 || blk_staged[blockIdx.x]) return;   // nothing worth a look in this tile, or the counting pass kept it all (uniform)
         mine = cnt_slots[(u64)blockIdx.x * 256 + tid];
         at = blk_off[blockIdx.x] + block_excl_scan_u32(mine, l4, nullptr);
     }
@@ -1012,10 +1024,10 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
         if (pal) {                                              // second pass starts with the k-mer itself (HTS:2781-2787)
             nc++;
             if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gi; slots[at].meta = SLOT_PAL_SELF; at++; }
-            else nslot++;
+            else { nslot++; spill = true; }                     // (kept slots are plain ones)
         }
         // one earlier record of the run (HTS:2753-2762): a comparison the reference makes, and perhaps a slot
-        auto visit = [&](u32 gj, u64 bj, u32 qj) {
+        auto visit = [&](u32 gj, u64 bj, u32 qj, int lj /* LDS slot of the partner, -1: it came from global memory */) {
             if (pal) {
                 nc += 4;
                 if (WRITE) for (u32 c = SLOT_PAL_FWD0; c <= SLOT_PAL_REV1; c++, at++) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = c; }
@@ -1030,13 +1042,18 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
                 if (mm > p.d) return;
             }
             if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = SLOT_PLAIN; at++; }
-            else nslot++;
+            else {
+                const u32 e = (lj >= 0 && nslot < 256u) ? atomicAdd(&s_n, 1u) : (u32)VT_QUOTA;
+                if (e < (u32)VT_QUOTA) { s_val[WRITE ? 0 : e] = ((u32)li << 16) | (u32)lj; s_own[WRITE ? 0 : e] = (uint16_t)((tid << 8) | nslot); }
+                else spill = true;
+                nslot++;
+            }
         };
         // walk back inside LDS: slots li-1 .. first  (a tight loop of its own: the common case)
         int j = li - 1;
         bool more = has_prev;
         while (more) {
-            visit((u32)s_key[j], SKB ? s_b[j] : 0ull, SKC ? s_c[j] : 0u);
+            visit((u32)s_key[j], SKB ? s_b[j] : 0ull, SKC ? s_c[j] : 0u, j);
             j--;
             more = j >= first && (u32)(s_key[j] >> 32) == code;
         }
@@ -1047,24 +1064,43 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
                 const u64 cj = codes[g];
                 if ((u32)(cj >> 32) != code) break;
                 nc = 0;
-                visit((u32)cj, SKB ? sk_b[g] : 0ull, SKC ? sk_c[g] : 0u);
+                visit((u32)cj, SKB ? sk_b[g] : 0ull, SKC ? sk_c[g] : 0u, -1);
                 ncand += nc;
             }
         }
     }
     if (!WRITE) {
-        cnt_slots[(u64)blockIdx.x * 256 + tid] = nslot;
-        u32 r = nslot;
         u64 c = ncand;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o, 64); c += __shfl_xor(c, o, 64); }
-        if ((tid & 63) == 0) { l4[tid >> 6] = r; c4[tid >> 6] = c; }
-        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((tid & 63) == 0) c4[tid >> 6] = c;
+        u32 total;
+        const u32 pre = block_excl_scan_u32(nslot, l4, &total);            // (its barriers also publish c4)
+        s_pre[WRITE ? 0 : tid] = pre;
+        const bool keep_all = !__syncthreads_or(spill) && total <= (u32)VT_QUOTA;      // (the barrier also publishes s_pre)
+        if (keep_all) {                                                     // the tile's slots, in thread order, at its place in the staging array
+            if ((u32)tid < total) {
+                const u32 e = s_val[WRITE ? 0 : tid], o = s_own[WRITE ? 0 : tid];
+                staged[(u64)blockIdx.x * VT_QUOTA + s_pre[WRITE ? 0 : (o >> 8)] + (o & 255u)] = ((u64)(u32)s_key[e >> 16] << 32) | (u32)s_key[e & 0xFFFFu];
+            }
+        } else cnt_slots[(u64)blockIdx.x * 256 + tid] = nslot;              // the WRITE pass walks this tile again
         if (tid == 0) {
-            blk_slots[blockIdx.x] = l4[0] + l4[1] + l4[2] + l4[3];
+            blk_slots[blockIdx.x] = total;
+            blk_staged[blockIdx.x] = keep_all ? 1 : 0;
             blk_cand[blockIdx.x] = c4[0] + c4[1] + c4[2] + c4[3];
         }
     }
+}
+
+// the kept slots of the tiles the counting pass could keep whole: staging array -> slot array
+__global__ __launch_bounds__(VT_QUOTA) void k_staged_slots(const u64 *__restrict__ staged, const u32 *__restrict__ blk_slots, const u8 *__restrict__ blk_staged,
+                                                           const u64 *__restrict__ blk_off, PairRec *__restrict__ slots)
+{
+    if (!blk_staged[blockIdx.x] || threadIdx.x >= blk_slots[blockIdx.x]) return;
+    const u64 e = staged[(u64)blockIdx.x * VT_QUOTA + threadIdx.x];
+    PairRec r;
+    r.p1 = (u32)(e >> 32); r.p2 = (u32)e; r.meta = SLOT_PLAIN;
+    slots[blk_off[blockIdx.x] + threadIdx.x] = r;
 }
 
 // One thread per slot: both K-mers from the packed genome, CompareAndReport; meta in place of the kind.  Also counts the
@@ -1777,24 +1813,27 @@ void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, con
 u64 verify_blocks(u64 n) { return (n + VT_TILE - 1) / VT_TILE; }
 template <bool WRITE>
 static void launch_candidates(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
-                              const u64 *blk_off, PairRec *slots, const u64 *sk_b, const u32 *sk_c)
+                              const u64 *blk_off, PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged)
 {
     if (!n) return;
     const dim3 g((unsigned)verify_blocks(n)), b(256);
-    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates<WRITE, true, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
-    else if (sk_b) hipLaunchKernelGGL((k_candidates<WRITE, true, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
-    else if (sk_c) hipLaunchKernelGGL((k_candidates<WRITE, false, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
-    else hipLaunchKernelGGL((k_candidates<WRITE, false, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c);
+    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates<WRITE, true, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
+    else if (sk_b) hipLaunchKernelGGL((k_candidates<WRITE, true, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
+    else if (sk_c) hipLaunchKernelGGL((k_candidates<WRITE, false, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
+    else hipLaunchKernelGGL((k_candidates<WRITE, false, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
 }
+u64 verify_staging_elems(u64 n) { return verify_blocks(n) * VT_QUOTA; }
 void launch_candidates_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
-                             const u64 *sk_b, const u32 *sk_c)
+                             const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged)
 {
-    launch_candidates<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c);
+    launch_candidates<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged);
 }
 void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, const u64 *blk_off,
-                             PairRec *slots, const u64 *sk_b, const u32 *sk_c)
+                             PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged)
 {
-    launch_candidates<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c);
+    if (!n) return;
+    hipLaunchKernelGGL(k_staged_slots, dim3((unsigned)verify_blocks(n)), dim3(VT_QUOTA), 0, s, staged, blk_slots, blk_staged, blk_off, slots);
+    launch_candidates<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged);
 }
 void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid)
 {
