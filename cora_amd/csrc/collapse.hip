@@ -184,6 +184,25 @@ __device__ __forceinline__ u64 fnv_of(const Mer<W> &m, u32 R)
     return h;
 }
 
+// the same for a read-mer known to hold no N (every reference window: k_win_count drops windows with one): three
+// instructions of seventeen fewer per base
+template <int W>
+__device__ __forceinline__ u64 fnv_of_clean(const Mer<W> &m, u32 R)
+{
+    u64 h = FNV_BASIS;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const u32 n = R > 32u * k ? min(32u, R - 32u * k) : 0u;
+        u64 c = m.c[k];
+        for (u32 j = 0; j < n; j++) {
+            const u32 ch = (ACGT_PACKED >> (8 * (u32)(c >> 62))) & 0xFFu;
+            h = (h ^ ch) * FNV_PRIME;
+            c <<= 2;
+        }
+    }
+    return h;
+}
+
 template <int W, class P>
 __device__ __forceinline__ void put_mer(P dst, const Mer<W> &m, u32 R)
 {
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(CT) void k_win_count(u64 G, u32 R, const u32 *__res
 
 template <int W>
 __global__ __launch_bounds__(CT) void k_win_emit(Src s, const u32 *__restrict__ wvalid, const u64 *__restrict__ blk_off,
-                                                 u64 *__restrict__ key, u32 *__restrict__ id)
+                                                 u64 *__restrict__ key, u32 *__restrict__ id, int clean_hash)
 {
     __shared__ u32 lds[4];
     const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(CT) void k_win_emit(Src s, const u32 *__restrict__ 
     Mer<W> m;
     canon<W>(s, (u32)g, m);
     const u64 at = blk_off[blockIdx.x] + r;
-    key[at] = fnv_of<W>(m, s.R); id[at] = (u32)g;
+    key[at] = clean_hash ? fnv_of_clean<W>(m, s.R) : fnv_of<W>(m, s.R); id[at] = (u32)g;
 }
 
 // ------------------------------------------------------------------ read-mers of the input
@@ -789,7 +808,8 @@ int run_impl(cora_hip_collapse *c)
     DBuf<u64> key, tkey;
     DBuf<u32> id, tid;
     RCQ(key.alloc(N + 1)); RCQ(tkey.alloc(N + 1)); RCQ(id.alloc(N + 1)); RCQ(tid.alloc(N + 1));
-    if (rj && G) LAUNCH_W(k_win_emit, dim3(grid_of(G, CT)), dim3(CT), s, src, wvalid.p, woff.p, key.p, id.p);
+    const int clean_hash = getenv("CORA_COLLAPSE_CLEAN_HASH") ? atoi(getenv("CORA_COLLAPSE_CLEAN_HASH")) : 0;   // the loop without the N test
+    if (rj && G) LAUNCH_W(k_win_emit, dim3(grid_of(G, CT)), dim3(CT), s, src, wvalid.p, woff.p, key.p, id.p, clean_hash);
     if (n_items) LAUNCH_W(k_read_keys, dim3(grid_of(n_items, CT)), dim3(CT), s, src, n_items, NW, key.p, id.p);
     CollapseCounters hc;
     HIPQ(hipMemcpyAsync(&hc, ctr.p, sizeof hc, hipMemcpyDeviceToHost, s));
