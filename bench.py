@@ -139,7 +139,7 @@ def run_steps(run, job, steps, sync):
         ts = time.perf_counter()
         run()
         st = job.stats()
-        if os.environ.get("CORA_TRACE"):
+        if os.environ.get("CORA_TRACE") or os.environ.get("RANK", "0") == "0":       # (a long run must not look hung)
             print("[bench] step wall %.3f ms  %s" % ((time.perf_counter() - ts) * 1e3, " ".join("%s=%.2f" % (k[3:], st[k]) for k in (
                 "ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish"))), file=sys.stderr, flush=True)
         sc_ms += st["ms_sort_scatter"]; sc_n += st["n_sort_scatter"]; sc_bytes += st["sort_scatter_bytes"]
@@ -201,6 +201,8 @@ def main():
     total_bases = int(sum(len(s) for _, s in contigs))
     del contigs
     t_gen = time.time() - t_gen
+    if rank == 0:
+        print("[bench] %s ready after %.1f s (%d ranks)" % (tag, t_gen, world), file=sys.stderr, flush=True)
     e2e = None
     if world == 1 and not a.no_extras:
         fa_path = os.path.join(tmp, "ref.fa")
@@ -228,7 +230,10 @@ def main():
         if sharded and os.environ.get("CORA_BENCH_FAIL_SHARDED"):      # rehearsal of the fall-back itself
             raise RuntimeError("CORA_BENCH_FAIL_SHARDED is set")
         for _ in range(a.warmup):
+            tw = time.perf_counter()
             run()
+            if rank == 0:
+                print("[bench] warm-up step %.3f s" % (time.perf_counter() - tw), file=sys.stderr, flush=True)
         sync()
     except Exception as e:                            # noqa: BLE001
         if not sharded:

@@ -263,6 +263,17 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
             stage[lpos[r]] = kw[r];
         }
     }
+    // 512-thread tiles fetch the other key word now: the key registers are free again, and the loads are in flight
+    // while the first word's runs are written (fetched only after that, every tile waited a whole memory latency there)
+    constexpr bool LATE_B = HAS_B && !PRE_B;
+    u64 lv[LATE_B ? RS_IPT : 1];
+    if (LATE_B) {
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) {
+            u32 li = l0 + r * 64;
+            lv[r] = (li < count) ? __builtin_nontemporal_load(oth_in + base + li) : 0;
+        }
+    }
     __syncthreads();
     u32 dst[RS_IPT];
 #pragma unroll
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            if (li < count) stage[lpos[r]] = PRE_B ? ov[r] : oth_in[base + li];
+            if (li < count) stage[lpos[r]] = PRE_B ? ov[r] : lv[r];
         }
         __syncthreads();
 #pragma unroll
@@ -377,7 +388,8 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     // records with a 4-byte payload go through 512-thread tiles of 8192 (their payload runs are twice as long: +9 % scatter
     // bandwidth; tools/spreadwrite.cpp shows what short unaligned runs cost: 3.8 TB/s at 136 B, 4.6 at 264 B), all others
     // through 256-thread tiles of 4096: two-word records need 140 VGPRs, which leaves 512-thread workgroups one per CU
-    // (measured at 2.9e9 records: 30.3 ms per pass against 27.1)
+    // (measured at 2.9e9 records: 30.3 ms per pass against 27.1).  1024-thread tiles of 16384 (one workgroup per CU, runs
+    // twice as long) were slower still: 21.9 ms per pass against 20.4 at 2.6e9 two-word records
     const u32 tile_recs = radix_sort_tile_records(keys.b != nullptr, keys.c != nullptr);
     const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
     const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;

@@ -47,7 +47,7 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     if (N >= (1ull << 32) - 1) return fail(19, "too many K-mers for 32-bit indices");
     DBuf<u64> head_flag;                        // one bit per record: opens a class
     DBuf<u32> mixed_list;
-    const u32 mixed_cap = 65536, long_cap = 4096;
+    const u32 mixed_cap = (u32)std::max<u64>(65536, N / 128), long_cap = 4096;     // 48 hash bits: a few thousand; 40 bits at 3e9 records: 4e6
     RCQ(x.trec.alloc(N)); RCQ(x.tgp.alloc(N)); RCQ(head_flag.alloc(((N + 255) / 256) * 4)); RCQ(mixed_list.alloc(mixed_cap));
     // Equal canonical keys have equal hashes: sort 12-byte (hash, position) records on the top hb hash bits
     // (6-7 passes) instead of 20-byte full keys on 2K bits (13 passes); collisions are found and repaired below.

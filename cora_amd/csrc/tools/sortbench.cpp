@@ -118,15 +118,19 @@ int main(int argc, char **argv)
             printf("x_hist mode %d: %.3f ms  %.0f GB/s\n", mode, ms / reps, 8.0 * n * reps / ms / 1e6);
         }
     }
-    struct Case { const char *name; bool hasc; int lo, hi; } cases[] = {
-        {"exact  (u64 hash + u32 pos, bits 16..64)", true, 16, 64},
-        {"seeds  (u64 code|pos, bits 32..64)", false, 32, 64},
+    u64 *b, *tb;
+    CK(hipMalloc(&b, n * 8)); CK(hipMalloc(&tb, n * 8));
+    struct Case { const char *name; bool hasc, hasb; int lo, hi; } cases[] = {
+        {"exact  (u64 hash + u32 pos, bits 16..64)", true, false, 16, 64},
+        {"seeds  (u64 code|pos, bits 32..64)", false, false, 32, 64},
+        {"seeds with sketches (u64 code|pos + u64 sketch, bits 96..128)", false, true, 96, 128},
     };
     for (const Case &cs : cases) {
         double tot = 0, sc = 0, scb = 0; u32 launches = 0;
         for (int r = 0; r < reps; r++) {
             k_fill<<<4096, 256, 0, s>>>(a, c, n, 7 + r);
             SortArrays k, t; k.a = a; t.a = ta; if (cs.hasc) { k.c = c; t.c = tc; }
+            if (cs.hasb) { k_fill<<<4096, 256, 0, s>>>(b, nullptr, n, 107 + r); k.b = b; t.b = tb; }
             SortTiming tm; tm.enabled = true;
             CK(hipEventRecord(e0, s));
             if (radix_sort(s, k, t, n, cs.lo, cs.hi, scr, &tm)) { fprintf(stderr, "sort failed\n"); return 1; }
@@ -135,7 +139,8 @@ int main(int argc, char **argv)
             if (r == 0) {      // check order on a sample
                 std::vector<u64> h(1 << 20);
                 CK(hipMemcpy(h.data(), k.a, h.size() * 8, hipMemcpyDeviceToHost));
-                const u64 m = (cs.hi - cs.lo) == 64 ? ~0ull : (((1ull << (cs.hi - cs.lo)) - 1) << cs.lo);
+                const int lo = cs.lo & 63, hi = cs.hi - (cs.lo - lo);
+                const u64 m = (hi - lo) == 64 ? ~0ull : (((1ull << (hi - lo)) - 1) << lo);
                 for (size_t i = 1; i < h.size() && i < n; i++) if ((h[i - 1] & m) > (h[i] & m)) { fprintf(stderr, "NOT SORTED at %zu\n", i); return 1; }
             }
         }
