@@ -83,7 +83,9 @@ int main(int argc, char **argv)
         std::cout << "homTable_setup (MI355X build): exact and inexact homology tables of a reference\n"
                      "  1 reference FASTA (with .fai)   2 read-mer length [33-64]   3 2-char split file\n"
                      "  4 exact table (out)             5 inexact table (out)       6 4-char split file\n"
-                     "  7 EXACT|BOTH                    8 mismatches [1-3]          9 FULL|ONLY_...\n";
+                     "  7 BOTH                          8 mismatches [1-3]          9 FULL\n"
+                     "  (EXACT alone and the ONLY_CONSTRUCT / ONLY_*COMPACT run modes of the reference, which stop at or start from its\n"
+                     "   internal pre-compact files, are not built: cora never issues them)\n";
         return 19;
     }
     const std::string ref_path = argv[1], exact_out = argv[4], inexact_out = argv[5];
@@ -136,7 +138,7 @@ int main(int argc, char **argv)
     make_parent_dir(inexact_out);
 
     if (what != "BOTH" || run_mode != "FULL") {
-        std::cout << "ERROR: this build runs 'BOTH ... FULL' (the only form cora issues, cora.cpp:1581-1587); got '" << what << "' '"
+        std::cout << "ERROR: this build runs 'BOTH ... FULL' (the only form cora issues, cora.cpp:1581-1587), not EXACT or the ONLY_* run modes; got '" << what << "' '"
                   << run_mode << "'" << std::endl;
         return 19;
     }
