@@ -436,6 +436,24 @@ extern "C" int cora_hip_test_pack(cora_hip_job *job, uint64_t *packed, uint32_t 
     return 0;
 }
 
+extern "C" int cora_hip_test_window_bits(cora_hip_job *job, uint32_t *fast, uint32_t *slow, uint64_t cap_words, uint64_t *n_words)
+{
+    if (!job || !job->have_ref) return fail(51, "no reference set");
+    PoolScope pool_scope(&job->pool);
+    const DevParams &dp = job->dp;
+    if (n_words) *n_words = dp.n_words;
+    if (dp.n_words > cap_words) return fail(19, "buffer too small: %llu words", (unsigned long long)dp.n_words);
+    RCQ(st_pack(job));
+    DBuf<u32> f, sl;
+    RCQ(f.alloc(dp.n_words)); RCQ(sl.alloc(dp.n_words));
+    launch_test_window_bits(job->stream, dp, job->bad.p, f.p, sl.p);
+    HIPQ(hipGetLastError());
+    HIPQ(hipMemcpyAsync(fast, f.p, dp.n_words * sizeof(u32), hipMemcpyDeviceToHost, job->stream));
+    HIPQ(hipMemcpyAsync(slow, sl.p, dp.n_words * sizeof(u32), hipMemcpyDeviceToHost, job->stream));
+    HIPQ(hipStreamSynchronize(job->stream));
+    return 0;
+}
+
 extern "C" int cora_hip_test_kmers(cora_hip_job *job, uint64_t *key_hi, uint64_t *key_lo, uint32_t *gpos, uint64_t cap, uint64_t *n_out)
 {
     if (!job || !job->have_ref) return fail(51, "no reference set");

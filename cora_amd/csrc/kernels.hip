@@ -102,6 +102,74 @@ __device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32 *lds4, u32 *total)
 // and one validity word.  Bases are read from the FASTA image: base `local` of a contig
 // sits at ctg_off + local + local / line_width (HTS:96-142: fixed line width, '\n' ends).
 // Upper-casing and "everything but ACGT is N" follow HTS:131-136.
+//
+// Fast path (all 32 bases inside the contig and not its last ones, lines of at least 33 bases, nothing but ACGTN in
+// either case and the line end where it belongs): the 33 bytes come in as three aligned 16-byte loads, the line end is
+// squeezed out, and letters become codes eight at a time: for A C G T, ((ch >> 1) ^ (ch >> 2)) & 3 = 0 1 2 3, and a byte
+// is a base iff it equals the letter its own code stands for.  Anything else takes the byte loop below, which is the
+// definition.
+constexpr u64 B01 = 0x0101010101010101ull, B7F = 0x7F7F7F7F7F7F7F7Full, B80 = 0x8080808080808080ull;
+__device__ __forceinline__ u64 nonzero_bytes(u64 x) { return (((x & B7F) + B7F) | x) & B80; }      // 0x80 in every byte of x that is not 0
+
+// eight letters (byte 0 = first base): codes into bits 15..0 (first base highest), not-ACGT flags into bits 7..0 alike;
+// false when some byte is neither ACGT nor N (in either case)
+__device__ __forceinline__ bool pack8(u64 c, u32 &codes, u32 &bads)
+{
+    const u64 u = c & 0xDFDFDFDFDFDFDFDFull;
+    const u64 c0 = ((u >> 1) ^ (u >> 2)) & B01, c1 = ((u >> 2) ^ (u >> 3)) & B01, cc = c0 & c1;
+    const u64 expect = 0x4141414141414141ull + (c0 << 1) + (c1 << 2) + (c1 << 1) + (cc << 3) + (cc << 1) + cc;   // A +2 C, +6 G, +19 T
+    const u64 bad = nonzero_bytes(u ^ expect);
+    const u64 not_n = nonzero_bytes(u ^ 0x4E4E4E4E4E4E4E4Eull);
+    if (bad & not_n) return false;
+    u64 y = __builtin_bswap64(c0 | (c1 << 1));               // first base in the top byte
+    y = (y | (y >> 6)) & 0x000F000F000F000Full;
+    y = (y | (y >> 12)) & 0x000000FF000000FFull;
+    codes = (u32)((y | (y >> 24)) & 0xFFFFull);
+    u64 z = __builtin_bswap64(bad >> 7);
+    z = (z | (z >> 7)) & 0x0003000300030003ull;
+    z = (z | (z >> 14)) & 0x0000000F0000000Full;
+    bads = (u32)((z | (z >> 28)) & 0xFFull);
+    return true;
+}
+
+__device__ __forceinline__ bool pack32_fast(const DevParams &p, const u8 *__restrict__ raw, u64 a0, u32 n /* bases before the line end */,
+                                            u64 &packed, u32 &badw)
+{
+    const uint4 *q = reinterpret_cast<const uint4 *>(raw + (a0 & ~15ull));
+    const uint4 v0 = q[0], v1 = q[1], v2 = q[2];
+    u64 w[7] = {((u64)v0.y << 32) | v0.x, ((u64)v0.w << 32) | v0.z, ((u64)v1.y << 32) | v1.x, ((u64)v1.w << 32) | v1.z,
+                ((u64)v2.y << 32) | v2.x, ((u64)v2.w << 32) | v2.z, 0ull};
+    if (a0 & 8) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) w[j] = w[j + 1];
+    }
+    const int sh = (int)(a0 & 7) * 8;
+    u64 b[5];                                               // bytes a0 .. a0+39
+#pragma unroll
+    for (int j = 0; j < 5; j++) b[j] = sh ? ((w[j] >> sh) | (w[j + 1] << (64 - sh))) : w[j];
+    if (n <= 32) {                                          // the line ends inside (or right behind) these bases: byte n must be it
+        u64 wn = b[0];
+#pragma unroll
+        for (int j = 1; j < 5; j++) if ((int)(n >> 3) == j) wn = b[j];
+        if (((wn >> ((n & 7) * 8)) & 0xFF) != (u64)'\n') return false;
+    }
+    packed = 0; badw = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u64 c = b[j];
+        if (n < 8u * (j + 1)) {                             // bytes from n on come from one place further on
+            const u64 d = (b[j] >> 8) | (b[j + 1] << 56);
+            if (n <= 8u * j) c = d;
+            else { const u64 m = (1ull << ((n - 8u * j) * 8)) - 1ull; c = (b[j] & m) | (d & ~m); }
+        }
+        u32 codes, bads;
+        if (!pack8(c, codes, bads)) return false;
+        packed |= (u64)codes << (48 - 16 * j);
+        badw |= bads << (24 - 8 * j);
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict__ raw, u64 *__restrict__ pk,
                                               u32 *__restrict__ bad, DevCounters *ctr)
 {
@@ -118,31 +186,38 @@ __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict_
             const u64 off0 = p.ctg_off[c];
             u64 line = local0 / p.line_width;
             u32 col = (u32)(local0 - line * p.line_width);
-            u32 errs = 0, others = 0;
-            badw = 0;
+            const u64 a0 = off0 + local0 + line;
+            bool done = false;
+            if (p.line_width >= 33 && local0 + 32 < len && a0 + 48 <= p.image_bytes + 16 && a0 + 33 <= p.image_bytes)
+                done = pack32_fast(p, raw, a0, p.line_width - col, packed, badw);
+            if (!done) {
+                u32 errs = 0, others = 0;
+                packed = 0;
+                badw = 0;
 #pragma unroll 4
-            for (int i = 0; i < 32; i++) {
-                const u64 local = local0 + i;
-                u32 code = 0, isbad = 1;
-                if (local < len) {
-                    const u64 at = off0 + local + line;
-                    u32 ch = (at < p.image_bytes) ? raw[at] : (u32)'\n';
-                    if (ch == '\n' || ch == '>') errs++;
-                    if (ch > 'Z') ch -= 32;
-                    isbad = 0;
-                    if (ch == 'A') code = 0; else if (ch == 'C') code = 1; else if (ch == 'G') code = 2; else if (ch == 'T') code = 3;
-                    else { isbad = 1; others += (ch != 'N'); }
-                    if (col + 1 == p.line_width || local + 1 == len) {      // a line must end here
-                        const u64 nl = at + 1;
-                        if (nl < p.image_bytes && raw[nl] != '\n') errs++;
+                for (int i = 0; i < 32; i++) {
+                    const u64 local = local0 + i;
+                    u32 code = 0, isbad = 1;
+                    if (local < len) {
+                        const u64 at = off0 + local + line;
+                        u32 ch = (at < p.image_bytes) ? raw[at] : (u32)'\n';
+                        if (ch == '\n' || ch == '>') errs++;
+                        if (ch > 'Z') ch -= 32;
+                        isbad = 0;
+                        if (ch == 'A') code = 0; else if (ch == 'C') code = 1; else if (ch == 'G') code = 2; else if (ch == 'T') code = 3;
+                        else { isbad = 1; others += (ch != 'N'); }
+                        if (col + 1 == p.line_width || local + 1 == len) {      // a line must end here
+                            const u64 nl = at + 1;
+                            if (nl < p.image_bytes && raw[nl] != '\n') errs++;
+                        }
+                        if (++col == p.line_width) { col = 0; line++; }
                     }
-                    if (++col == p.line_width) { col = 0; line++; }
+                    packed |= (u64)code << (62 - 2 * i);
+                    badw |= isbad << (31 - i);
                 }
-                packed |= (u64)code << (62 - 2 * i);
-                badw |= isbad << (31 - i);
+                if (errs) atomicAdd(&ctr->format_errors, (unsigned long long)errs);
+                if (others) atomicAdd(&ctr->other_letters, (unsigned long long)others);
             }
-            if (errs) atomicAdd(&ctr->format_errors, (unsigned long long)errs);
-            if (others) atomicAdd(&ctr->other_letters, (unsigned long long)others);
         }
     }
     pk[w] = packed;
@@ -150,19 +225,60 @@ __global__ __launch_bounds__(256) void k_pack(DevParams p, const u8 *__restrict_
 }
 
 // ------------------------------------------------------------------ valid windows -> keys
-__global__ __launch_bounds__(256) void k_kmer_count(DevParams p, const u32 *__restrict__ bad, u32 *__restrict__ block_counts,
-                                                    u32 *__restrict__ valid)
+// One thread per word of 32 positions: the validity bits of positions 32w .. 32w+127 as a 128-bit string (first position
+// in the top bit), "some bad base in [i, i+K)" for all 32 starts i at once by doubling (OR of the string shifted by 1, 2,
+// 4, 8, 16 and K-32: six steps instead of 32 window tests of three loads each), and the Q4 case (window_ok) for the few
+// starts whose window is followed by a bad base.  Per block of 256 positions (8 words = 8 neighbouring lanes): the count,
+// as the record emission wants it.  window_ok() stays the definition; tests compare the two (cora_hip_test_window_bits).
+__device__ __forceinline__ void shl128(u64 &hi, u64 &lo, int s /* 1..63 */)
 {
-    __shared__ u32 wsum[4];
-    const u64 g = p.pos_base + (u64)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = (g < p.G) && window_ok(p, bad, g);
-    const u64 bal = __ballot(ok);
-    const int lane = threadIdx.x & 63;
-    if (lane == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
+    hi = (hi << s) | (lo >> (64 - s));
+    lo <<= s;
+}
+__device__ __forceinline__ u32 window_bits(const DevParams &p, const u32 *__restrict__ bad, u64 w)
+{
+    if (w >= p.n_words) return 0;                       // (bad[] has 4 words of padding behind n_words, all ones)
+    const u64 x_hi = ((u64)bad[w] << 32) | bad[w + 1], x_lo = ((u64)bad[w + 2] << 32) | bad[w + 3];
+    u64 hi = x_hi, lo = x_lo;
+#pragma unroll
+    for (int sft = 1; sft <= 16; sft <<= 1) { u64 h = hi, l = lo; shl128(h, l, sft); hi |= h; lo |= l; }   // any bad in [i, i+32)
+    if (p.K > 32) { u64 h = hi, l = lo; shl128(h, l, p.K - 32); hi |= h; }                                 // ... in [i, i+K)
+    u32 ok = ~(u32)(hi >> 32);
+    // Q4 (HTS:1954-1981): the base behind the window is bad -> window_ok decides (a handful of positions per N run)
+    u64 nh = x_hi, nl = x_lo;
+    if (p.K < 64) shl128(nh, nl, p.K); else nh = nl;
+    u32 q = ok & (u32)(nh >> 32);
+    while (q) {
+        const int i = __clz((int)q);
+        q &= ~(0x80000000u >> i);
+        if (!window_ok(p, bad, (w << 5) + (u64)i)) ok &= ~(0x80000000u >> i);
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void k_kmer_count(DevParams p, const u32 *__restrict__ bad, u32 *__restrict__ block_counts,
+                                                    u32 *__restrict__ valid, u32 n_blocks)
+{
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;            // word t of the range: 8 words per block of 256 positions
+    const bool in = t < (u64)n_blocks * 8;
+    const u64 w = (p.pos_base >> 5) + t;
+    const u32 ok = in ? window_bits(p, bad, w) : 0u;
     // the window-validity bitmap (bit 31-i of word w = position 32w+i), kept for the later passes over positions
-    if (valid && (lane == 0 || lane == 32)) valid[g >> 5] = __brev((u32)(bal >> lane));
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (in && valid) valid[w] = ok;
+    u32 c = (u32)__popc(ok);
+    c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
+    if (in && (threadIdx.x & 7) == 0) block_counts[t >> 3] = c;
+}
+
+// test hook: the validity word of every 32 positions by the bit-parallel path and by window_ok, one thread per word
+__global__ __launch_bounds__(256) void k_test_window_bits(DevParams p, const u32 *__restrict__ bad, u32 *__restrict__ fast, u32 *__restrict__ slow)
+{
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= p.n_words) return;
+    fast[w] = window_bits(p, bad, w);
+    u32 r = 0;
+    for (int i = 0; i < 32; i++) if (window_ok(p, bad, (w << 5) + (u64)i)) r |= 0x80000000u >> i;
+    slow[w] = r;
 }
 
 // canonical key = lexicographically smaller of forward / reverse complement (HTS:2551-2565)
@@ -1699,7 +1815,7 @@ void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 
 }
 void launch_kmer_count(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 n_blocks)
 {
-    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, p, bad, block_counts, (u32 *)nullptr);
+    hipLaunchKernelGGL(k_kmer_count, grid_for((u64)n_blocks * 8), dim3(256), 0, s, p, bad, block_counts, (u32 *)nullptr, n_blocks);
 }
 void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off, u32 n_blocks,
                       u64 *key_hi, u64 *key_lo, u32 *gpos)
@@ -1989,7 +2105,11 @@ void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, 
     if (!n_blocks) return;
     DevParams q = p;
     q.pos_base = (u64)block_lo * 256;
-    hipLaunchKernelGGL(k_kmer_count, dim3(n_blocks), dim3(256), 0, s, q, bad, block_counts, valid);
+    hipLaunchKernelGGL(k_kmer_count, grid_for((u64)n_blocks * 8), dim3(256), 0, s, q, bad, block_counts, valid, n_blocks);
+}
+void launch_test_window_bits(hipStream_t s, const DevParams &p, const u32 *bad, u32 *fast, u32 *slow)
+{
+    hipLaunchKernelGGL(k_test_window_bits, grid_for(p.n_words), dim3(256), 0, s, p, bad, fast, slow);
 }
 void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *valid, const u64 *block_off, u32 block_lo,
                                    u32 n_blocks, u64 *rec, u32 *gpos)

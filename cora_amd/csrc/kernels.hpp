@@ -62,6 +62,7 @@ struct DevCounters {
 // ---- launch wrappers (all asynchronous on stream s) ----
 void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr);
 void launch_kmer_count(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 n_blocks);
+void launch_test_window_bits(hipStream_t s, const DevParams &p, const u32 *bad, u32 *fast /* window_bits */, u32 *slow /* window_ok */);
 void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *bad, const u64 *block_off,
                       u32 n_blocks, u64 *key_hi, u64 *key_lo, u32 *gpos);
 void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);

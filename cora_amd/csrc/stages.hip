@@ -47,12 +47,13 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     if (N >= (1ull << 32) - 1) return fail(19, "too many K-mers for 32-bit indices");
     DBuf<u64> head_flag;                        // one bit per record: opens a class
     DBuf<u32> mixed_list;
-    const u32 mixed_cap = (u32)std::max<u64>(65536, N / 128), long_cap = 4096;     // 48 hash bits: a few thousand; 40 bits at 3e9 records: 4e6
+    const u32 mixed_cap = (u32)std::max<u64>(65536, N / 128), long_cap = 65536;    // 40 hash bits at 3e9 records: 2e6 listed places
     RCQ(x.trec.alloc(N)); RCQ(x.tgp.alloc(N)); RCQ(head_flag.alloc(((N + 255) / 256) * 4)); RCQ(mixed_list.alloc(mixed_cap));
     // Equal canonical keys have equal hashes: sort 12-byte (hash, position) records on the top hb hash bits
     // (6-7 passes) instead of 20-byte full keys on 2K bits (13 passes); collisions are found and repaired below.
-    // About N^2 / 2^(hb+1) pairs of different K-mers collide: a few thousand with 40 bits up to 2^27 records, with 48 up to 2^32.
-    const int hb = job->hash_bits ? job->hash_bits : (N <= (1ull << 27) ? 40 : 48);
+    // About N^2 / 2^(hb+1) pairs of different K-mers collide: a thousand at 64 M records, 2e6 at 3e9 -- repaired in 3 ms,
+    // where a sixth pass over 3e9 records costs 20 (48 bits: CORA_HASH_BITS=48).
+    const int hb = job->hash_bits ? job->hash_bits : 40;
     SortArrays keys, tmp;
     keys.a = x.rec.p; keys.c = x.gp.p; tmp.a = x.trec.p; tmp.c = x.tgp.p;
     if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");

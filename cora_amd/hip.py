@@ -21,7 +21,7 @@ BIN_DIR = os.path.join(_HERE, "bin")
 EXPORTS = [
     "cora_hip_init", "cora_hip_shutdown", "cora_hip_last_error", "cora_hip_job_create", "cora_hip_job_destroy",
     "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_run_multi", "cora_hip_device_count", "cora_hip_job_tables", "cora_hip_job_stats",
-    "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers",
+    "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers", "cora_hip_test_window_bits",
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
     "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_seed_sketch", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
     "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
@@ -131,6 +131,7 @@ def lib():
         L.cora_hip_test_list_sort.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.cora_hip_test_pack.argtypes = [C.c_void_p] * 5
         L.cora_hip_test_kmers.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
+        L.cora_hip_test_window_bits.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p]
         L.cora_hip_shard_begin.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cora_hip_shard_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cora_hip_shard_slot_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -369,6 +370,15 @@ class Job:
         n = C.c_uint64()
         _check(lib().cora_hip_test_kmers(self._h, hi.ctypes.data, lo.ctypes.data, gp.ctypes.data, cap, C.byref(n)))
         return hi[:n.value], lo[:n.value], gp[:n.value]
+
+    def window_bits(self):
+        """(fast, slow): the window-validity bitmap by the bit-parallel path and by the per-position definition"""
+        cap = len(self._image) // 32 + 64 * 1024
+        fast = np.zeros(cap, dtype=np.uint32)
+        slow = np.zeros(cap, dtype=np.uint32)
+        n = C.c_uint64()
+        _check(lib().cora_hip_test_window_bits(self._h, fast.ctypes.data, slow.ctypes.data, cap, C.byref(n)))
+        return fast[:n.value], slow[:n.value]
 
     def close(self):
         if self._h:

@@ -386,6 +386,10 @@ int cora_hip_test_list_sort(uint32_t *elems, uint64_t n, int forced_depth);
 int cora_hip_test_pack(cora_hip_job *job, uint64_t *packed, uint32_t *bad, uint64_t *contig_start, uint64_t *padded_len);
 /* Canonical keys of all valid windows, in position order (after set_reference). */
 int cora_hip_test_kmers(cora_hip_job *job, uint64_t *key_hi, uint64_t *key_lo, uint32_t *gpos, uint64_t cap, uint64_t *n_out);
+/* "Is there a K-mer window at position g" (HTS:2619-2636 minus the case of HTS:1954-1981) for all positions, one bit each
+ * (bit 31-(g%32) of word g/32), computed twice: fast[] by the 32-positions-at-once path the build uses, slow[] by the
+ * per-position definition.  cap_words >= ceil(G/32) (n_words receives it). */
+int cora_hip_test_window_bits(cora_hip_job *job, uint32_t *fast, uint32_t *slow, uint64_t cap_words, uint64_t *n_words);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,39 @@ def test_reference_without_any_repeat_gives_empty_tables(sharded, tmp_path):
     assert (en, inn, len(ex), len(inx)) == (0, 0, 0, 0)
 
 
+@pytest.mark.parametrize("K", [33, 47, 50, 63, 64])
+def test_window_bitmap_32_positions_at_once_equals_the_definition(K, tmp_path):
+    """k_kmer_count derives the validity of 32 window starts per thread from the N/pad bitmap by shifts; window_ok is the
+    per-position definition (HTS:2619-2636, minus HTS:1954-1981's final stretch of exactly K bases).  Contigs full of
+    N runs, with N-free stretches of K-1, K, K+1 bases before N runs and before contig ends, short contigs, and starts
+    at every word phase."""
+    rs = np.random.RandomState(100 + K)
+    contigs = []
+    for c in range(12):
+        parts = []
+        for _ in range(int(rs.randint(3, 40))):
+            kind = rs.randint(0, 4)
+            n_free = int(K + rs.randint(-2, 3)) if kind == 0 else int(rs.randint(1, 4 * K))
+            parts.append(synth.random_seq(rs, n_free))
+            parts.append(synth.seq_from_str("N" * int(rs.randint(1, 70))))
+        tail = [K - 1, K, K + 1, 2 * K, 5][c % 5]                    # the final stretch: the Q4 case and its neighbours
+        parts.append(synth.random_seq(rs, tail))
+        if c % 3 == 0:
+            parts.insert(0, synth.random_seq(rs, K))                # a contig that starts with exactly K bases, then N
+        contigs.append(("c%d" % c, np.concatenate(parts)))
+    contigs.append(("exact", synth.random_seq(rs, K + 1)))          # one window, ending one base before the end
+    fa = str(tmp_path / "w.fa")
+    synth.write_fasta(fa, contigs, 61)
+    job = hip.Job(K, 1, helpers.split_path("phys", 1), helpers.split_path("par", 1))
+    try:
+        job.set_reference_file(fa)
+        fast, slow = job.window_bits()
+    finally:
+        job.close()
+    assert fast.size > 100 and slow.any()
+    assert np.array_equal(fast, slow)
+
+
 @pytest.mark.parametrize("K,d", [(36, 3), (50, 2)])
 def test_low_complexity_and_iupac(K, d, tmp_path):
     """Tandem repeats make classes of thousands of entries, lists far beyond 16 items and runs full of tied targets
