@@ -924,19 +924,33 @@ __global__ __launch_bounds__(256) void k_seed_codes(DevParams p, const u64 *__re
     out[r] = ((u64)(fw <= rc ? fw : rc) << 32) | g;          // canonical code (HTS:2732-2744)
 }
 
-// seed_code with the seed count known at compile time: the left positions s, s+NS, ... are constants (all inside the first
-// 32 bases), the right ones are constants counted from the K-mer's end, so `tail` holds the last 32 bases right-aligned.
+// seed_code with the seed count known at compile time.  A seed's bases sit NS apart, so a code is two strided gathers:
+// the left positions s, s+NS, ... from the K-mer's first word, the mirrored right ones from `tail` = its last 32 bases
+// right-aligned.  gather_stride compacts eight 2-bit items that lie 2 NS bits apart (item j at bit 2 NS j) into 16
+// adjacent bits (item j at bit 2j) in three mask-and-shift steps; the loop over bases it replaced cost 250 VALU
+// instructions per representative and made k_seed_codes_all ALU-bound.
+template <int NS>
+__device__ __forceinline__ u32 gather_stride(u64 x)
+{
+    constexpr int D = 2 * NS;
+    constexpr u64 M0 = (3ull) | (3ull << D) | (3ull << (2 * D)) | (3ull << (3 * D)) | (3ull << (4 * D)) | (3ull << (5 * D)) | (3ull << (6 * D)) | (3ull << (7 * D));
+    constexpr u64 M1 = (0xFull) | (0xFull << (2 * D)) | (0xFull << (4 * D)) | (0xFull << (6 * D));
+    constexpr u64 M2 = (0xFFull) | (0xFFull << (4 * D));
+    x &= M0;
+    x = (x | (x >> (D - 2))) & M1;
+    x = (x | (x >> (2 * D - 4))) & M2;
+    x = (x | (x >> (4 * D - 8))) & 0xFFFFull;
+    return (u32)x;
+}
 template <int NS>
 __device__ __forceinline__ u32 seed_code_fixed(u64 hi, u64 tail, int s /*0-based seed*/, int q)
 {
-    u32 v = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) if (j < q) v = (v << 2) | ((u32)(hi >> (62 - 2 * (s + NS * j))) & 3u);
-#pragma unroll
-    for (int j = 0; j < 8; j++) if (j >= q) v = (v << 4) | 3u;
-#pragma unroll
-    for (int j = 7; j >= 0; j--) if (j < q) v = (v << 2) | ((u32)(tail >> (2 * (s + NS * j))) & 3u);
-    return v;
+    // left: base s + NS j at bits 62 - 2 (s + NS j) of hi; shifted so that j = 7 is item 0, the result has j = 0 on top
+    const u32 left = gather_stride<NS>(hi >> (62 - 2 * s - 14 * NS)) >> (16 - 2 * q);
+    // right: base s + NS j from the end at bits 2 (s + NS j) of tail: item j, j = 0 lowest
+    const u32 right = gather_stride<NS>(tail >> (2 * s)) & ((1u << (2 * q)) - 1u);
+    const u32 fill = q < 8 ? (0x33333333u >> (4 * q)) << (2 * q) : 0u;        // (8 - q) literal A,T pairs in the middle
+    return (q < 8 ? left << (32 - 2 * q) : left << 16) | fill | right;
 }
 
 // All seeds of a run in one pass over the representatives: one window load, NS codes, and -- because a block covers
