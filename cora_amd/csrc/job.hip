@@ -57,6 +57,8 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
     if (const char *e = getenv("CORA_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) j->host_threads = v; }
     if (hipStreamCreate(&j->stream) != hipSuccess) { delete j; return fail(100, "hipStreamCreate failed"); }
     for (auto &e : j->ev) if (hipEventCreate(&e) != hipSuccess) { delete j; return fail(100, "hipEventCreate failed"); }
+    if (hipStreamCreateWithFlags(&j->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete j; return fail(100, "hipStreamCreate failed"); }
+    for (auto &e : j->ev_copy) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete j; return fail(100, "hipEventCreate failed"); }
     *out = j;
     return 0;
 }
@@ -72,6 +74,8 @@ extern "C" void cora_hip_job_destroy(cora_hip_job *job)
     job->pk.release(); job->bad.release(); job->ctr.release();
     job->pool.destroy();
     for (auto &e : job->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : job->ev_copy) if (e) (void)hipEventDestroy(e);
+    if (job->copy_stream) { (void)hipStreamSynchronize(job->copy_stream); (void)hipStreamDestroy(job->copy_stream); }
     if (job->stream) (void)hipStreamDestroy(job->stream);
     delete job;
 }
@@ -91,6 +95,7 @@ int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_
     if (!job->prm.chr_short && n_contigs > 127)
         return fail(19, "%d contigs need the 2-byte layout (homTable_setup_L; cora.cpp:25,488-493)", n_contigs);
     if (n_contigs > 65530) return fail(19, "too many contigs (%d)", n_contigs);                                            // HTS:23-27
+    if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }
     HostGenome &hg = job->hg;
     hg.gstart.assign(n_contigs + 1, 0);
     hg.len.assign(n_contigs, 0);
@@ -174,7 +179,17 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     HIPQ(hipEventRecord(job->ev[0], s));
 
     // ---- stage 1: pack, hashed K-mer records (HTS:2499-2565) ----
+    if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }   // (a run that failed half-way)
     RCQ(st_pack(job));
+    {
+        // the packed reference starts its way to the host now (0.25 B per base over PCIe beside 0.8 s of kernels): lists
+        // with tied targets are finished there and read their K-mers from it (st_items_finish)
+        RCQ(job->h_packed.reserve(dp.n_words + 4));
+        HIPQ(hipEventRecord(job->ev_copy[4], s));
+        HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[4], 0));
+        HIPQ(hipMemcpyAsync(job->h_packed.p, job->pk.p, (dp.n_words + 4) * sizeof(u64), hipMemcpyDeviceToHost, job->copy_stream));
+        job->packed_in_flight = true;
+    }
     ExactLocal x;
     RCQ(st_kmers(job, 0, (u32)((dp.G + 255) / 256), x.rec, x.gp, x.N));
     st.kmers = x.N;
@@ -265,6 +280,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         ps.pairs.release();
         RCQ(st_items_finish(job, ik, im, M, fst, host_ms));
     }
+    if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }
     st.exact_nodes = fst.exact_nodes; st.inexact_nodes = fst.inexact_nodes;
     st.dirty_nodes = fst.dirty_nodes; st.big_nodes = fst.big_nodes;
     (void)hipEventElapsedTime(&st.ms_pack, job->ev[0], job->ev[1]);

@@ -371,26 +371,27 @@ __global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64
 // After the sort on the top `hb` hash bits: head_flag[i] = 1 when record i opens a class.  Records with
 // equal truncated hashes have their canonical keys re-read from the packed genome and compared; a key
 // SMALLER than its predecessor's inside an equal-hash run means two different keys collided and are not
-// grouped yet: such positions are listed for k_mixed_fix.
+// grouped yet: such positions are marked in mixed_mask (one ballot word per wave, like the heads; the list k_mixed_fix
+// wants comes from k_mask_count / k_mask_emit.  A shared counter here cost 12 ns per listed place: 23 ms for the 2e6
+// places of a 3e9-record sort on 40 hash bits).
 __global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ rec,
                                                      const u32 *__restrict__ gpos, u64 n, int hb, u64 *__restrict__ head_mask,
-                                                     u32 *__restrict__ mixed_list, u32 mixed_cap, DevCounters *ctr)
+                                                     u64 *__restrict__ mixed_mask)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     u32 head = 0;
+    bool mixed = false;
     if (i < n) head = 1;
     if (i < n && i > 0 && (rec[i] >> (64 - hb)) == (rec[i - 1] >> (64 - hb))) {
         u64 ah, al, bh, bl;
         canonical_at(p, pk, gpos[i - 1], ah, al);
         canonical_at(p, pk, gpos[i], bh, bl);
         if (ah == bh && al == bl) head = 0;
-        else if (bh < ah || (bh == ah && bl < al)) {
-            const unsigned long long at = atomicAdd(&ctr->n_mixed, 1ull);      // rare: hash collisions only
-            if (at < mixed_cap) mixed_list[at] = (u32)i;
-        }
+        else mixed = bh < ah || (bh == ah && bl < al);
     }
     const u64 bal = __ballot(head != 0);                    // bit l of word i/64 = record 64*(i/64)+l opens a class
-    if ((threadIdx.x & 63) == 0) head_mask[i >> 6] = bal;
+    const u64 bam = __ballot(mixed);
+    if ((threadIdx.x & 63) == 0) { head_mask[i >> 6] = bal; mixed_mask[i >> 6] = bam; }
 }
 
 // One thread per listed position.  The run of equal truncated hashes around it is found by binary search (the records
@@ -1601,9 +1602,9 @@ __global__ __launch_bounds__(256) void k_node_write(DevParams p, int cw, const u
                                                     const u32 *__restrict__ size, const u64 *__restrict__ off, const u32 *__restrict__ hflag,
                                                     const u64 *__restrict__ hidx, const u64 *__restrict__ hoff, const u32 *__restrict__ node_tie,
                                                     u8 *__restrict__ stream, HostNode *__restrict__ hnodes, u64 *__restrict__ h_key,
-                                                    u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen, u32 *__restrict__ ord)
+                                                    u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen, u32 *__restrict__ ord, u32 node_lo)
 {
-    const u32 nd = blockIdx.x * 256 + threadIdx.x;
+    const u32 nd = node_lo + blockIdx.x * 256 + threadIdx.x;           // lists node_lo .. n_nodes-1
     if (nd >= n_nodes) return;
     const u32 a = node_start[nd], b = node_start[nd + 1];
     if (hflag[nd]) {
@@ -1816,11 +1817,11 @@ void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node
                                     n_nodes, size, hflag, hcnt, ctr);
 }
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
-                       const u32 *node_start, u32 n_nodes, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
+                       const u32 *node_start, u32 node_lo, u32 node_hi, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
                        const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen, u32 *ord)
 {
-    if (n_nodes) hipLaunchKernelGGL(k_node_write, grid_for(n_nodes), dim3(256), 0, s, p, cw, item_key, item_meta, blen, node_start, n_nodes,
-                                    size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen, ord);
+    if (node_hi > node_lo) hipLaunchKernelGGL(k_node_write, grid_for(node_hi - node_lo), dim3(256), 0, s, p, cw, item_key, item_meta, blen, node_start,
+                                              node_hi, size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen, ord, node_lo);
 }
 
 void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr)
@@ -1845,9 +1846,9 @@ void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCo
     if (p.n_contigs) hipLaunchKernelGGL(k_contig_scan, dim3(p.n_contigs), dim3(256), 0, s, p, bad, ctr);
 }
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
-                        u64 *head_mask, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr)
+                        u64 *head_mask, u64 *mixed_mask)
 {
-    if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_mask, mixed_list, mixed_cap, ctr);
+    if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_mask, mixed_mask);
 }
 void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u64 *head_mask, const u32 *mixed_list,
                       u32 n_mixed, u32 *claim, u64 *long_runs, u32 long_cap, DevCounters *ctr)

@@ -68,7 +68,7 @@ void launch_kmer_emit(hipStream_t s, const DevParams &p, const u64 *pk, const u3
 void launch_contig_check(hipStream_t s, const DevParams &p, const u32 *gpos_by_position, u64 n, DevCounters *ctr);
 void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCounters *ctr);
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
-                        u64 *head_mask /* [ceil(n/256)*4], bit l of word w = record 64w+l */, u32 *mixed_list, u32 mixed_cap, DevCounters *ctr);
+                        u64 *head_mask /* [ceil(n/256)*4], bit l of word w = record 64w+l */, u64 *mixed_mask /* same shape: places for k_mixed_fix */);
 void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u64 *head_mask,
                       const u32 *mixed_list, u32 n_mixed, u32 *claim /* zeroed bitmap over the records */,
                       u64 *long_runs /* [2 * long_cap] (start, end) of runs above 64 records */, u32 long_cap, DevCounters *ctr);
@@ -129,8 +129,8 @@ void launch_run_dirty(hipStream_t s, const u32 *node_tie, const u64 *run_excl, c
 void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node_start, const int16_t *blen, const u64 *run_excl,
                       const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, DevCounters *ctr);
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
-                       const u32 *node_start, u32 n_nodes, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
-                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen,
+                       const u32 *node_start, u32 node_lo, u32 node_hi /* lists node_lo .. node_hi-1 */, const u32 *size, const u64 *off,
+                       const u32 *hflag, const u64 *hidx, const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen,
                        u32 *ord /* [items] scratch of the lists above 16 items */);
 void launch_test_list_sort(hipStream_t s, u32 *e, u64 n, long forced_depth);
 

@@ -59,8 +59,21 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
     DevCounters h;
     ZERO_COUNTERS(job, n_mixed, 2);                              // n_mixed, fallback
-    launch_same_detect(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_list.p, mixed_cap, job->ctr.p);
-    RCQ(read_counters(job, h));
+    {
+        // heads and the places where an equal-hash run holds its keys out of order; the latter as a list, in record order
+        const u64 n_words = (N + 63) / 64, nb = (n_words + 255) / 256;
+        DBuf<u64> mixed_mask, boff, scr0, tot0;
+        DBuf<u32> bcnt;
+        RCQ(mixed_mask.alloc(((N + 255) / 256) * 4)); RCQ(bcnt.alloc(nb)); RCQ(boff.alloc(nb)); RCQ(scr0.alloc(scan_scratch_elems(nb))); RCQ(tot0.alloc(1));
+        launch_same_detect(s, dp, job->pk.p, keys.a, keys.c, N, hb, head_flag.p, mixed_mask.p);
+        launch_mask_count(s, mixed_mask.p, n_words, bcnt.p);
+        if (exclusive_scan_u32_to_u64(s, bcnt.p, boff.p, nb, scr0.p, tot0.p)) return fail(100, "scan launch failed");
+        u64 n_mixed = 0;
+        HIPQ(hipMemcpyAsync(&n_mixed, tot0.p, sizeof n_mixed, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        h.n_mixed = n_mixed;
+        if (n_mixed && n_mixed <= mixed_cap) launch_mask_emit(s, mixed_mask.p, n_words, boff.p, mixed_list.p);
+    }
     bool fallback = false;
     st.hash_mixed_runs += h.n_mixed;
     if (h.n_mixed > mixed_cap) fallback = true;
@@ -360,7 +373,16 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         if (exclusive_scan_u32_to_u64(s, hcnt.p, hoff.p, nn, scr.p, tots.p + 2)) return fail(100, "scan launch failed");
         u64 totals[3] = {0, 0, 0};                          // stream bytes, host lists, their items
         HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
+        // the byte stream is written and sent in up to four pieces of consecutive lists: where each piece starts
+        constexpr int PIECES = 4;
+        const int pieces = nn >= (1u << 20) ? PIECES : 1;
+        u32 piece_node[PIECES + 1];
+        u64 piece_off[PIECES + 1];
+        for (int c = 0; c <= pieces; c++) piece_node[c] = (u32)((u64)nn * c / pieces) & ~255u;
+        piece_node[pieces] = nn;
+        for (int c = 1; c < pieces; c++) HIPQ(hipMemcpyAsync(&piece_off[c], noff.p + piece_node[c], sizeof(u64), hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
+        piece_off[0] = 0; piece_off[pieces] = totals[0];
         trace_mark(job, "items: sizes + scans", 5);
         DBuf<u8> stream;
         DBuf<HostNode> hnodes;
@@ -370,15 +392,25 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         DBuf<u32> ord;
         RCQ(ord.alloc(M));
         RCQ(stream.alloc(totals[0])); RCQ(hnodes.alloc(totals[1])); RCQ(hk.alloc(totals[2])); RCQ(hm.alloc(totals[2])); RCQ(hbl.alloc(totals[2]));
-        launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, nn, nsize.p, noff.p, hflag.p, hidx.p, hoff.p, node_tie.p, stream.p,
-                          hnodes.p, hk.p, hm.p, hbl.p, ord.p);
+        RCQ(job->h_stream.reserve(totals[0]));
+        stream_host.p = job->h_stream.p; stream_host.n = totals[0];
+        for (int c = 0; c < pieces; c++) {
+            launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, piece_node[c], piece_node[c + 1], nsize.p, noff.p, hflag.p, hidx.p, hoff.p,
+                              node_tie.p, stream.p, hnodes.p, hk.p, hm.p, hbl.p, ord.p);
+            // a piece leaves on the copy stream as soon as it is written, while the next one is being written (PCIe at
+            // 55 GB/s takes longer over the whole stream than k_node_write does)
+            HIPQ(hipEventRecord(job->ev_copy[c], s));
+            HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[c], 0));
+            if (piece_off[c + 1] > piece_off[c])
+                HIPQ(hipMemcpyAsync(job->h_stream.p + piece_off[c], stream.p + piece_off[c], piece_off[c + 1] - piece_off[c], hipMemcpyDeviceToHost,
+                                    job->copy_stream));
+        }
         HIPQ(hipGetLastError());
-        // Wait for the kernels BEFORE queueing the copies to the host.  Queued behind pending kernels, these copies made
-        // the second run of every job 5.5 ms slower (once: a runtime-internal set-up on that path; bisected with
-        // CORA_SYNC_MASK).  The copies need the kernels' results anyway, so the wait costs nothing.
+        // Wait for the kernels BEFORE queueing the small copies to the host on the main stream.  Queued behind pending
+        // kernels, such copies made the second run of every job 5.5 ms slower (once: a runtime-internal set-up on that
+        // path; bisected with CORA_SYNC_MASK).  The copies need the kernels' results anyway, so the wait costs nothing.
         HIPQ(hipStreamSynchronize(s));
         trace_mark(job, "items: write bytes", 6);
-        RCQ(d2h(job, job->h_stream, stream_host, (const u8 *)stream.p, totals[0]));
         RCQ(d2h(job, job->h_hnodes, hnodes_host, (const HostNode *)hnodes.p, totals[1]));
         RCQ(d2h(job, job->h_key, ir.key, (const u64 *)hk.p, totals[2]));
         RCQ(d2h(job, job->h_meta, ir.meta, (const u32 *)hm.p, totals[2]));
@@ -386,8 +418,12 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         RCQ(read_counters(job, h));
         device_nodes = h.emitted_nodes;
         big_nodes = h.big_nodes;
-        if (h.n_dirty) RCQ(d2h(job, job->h_packed, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
+        if (h.n_dirty) {
+            if (job->packed_in_flight) { packed_host.p = job->h_packed.p; packed_host.n = dp.n_words + 4; }     // sent right after k_pack (job.hip)
+            else RCQ(d2h(job, job->h_packed, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
+        }
         HIPQ(hipStreamSynchronize(s));
+        HIPQ(hipStreamSynchronize(job->copy_stream));
         trace_mark(job, "items: copies to host", 7);
         // list starts of the compacted host items
         RCQ(job->h_node_start.reserve(totals[1] + 1));
