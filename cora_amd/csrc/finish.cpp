@@ -326,7 +326,8 @@ bool serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
 // The device wrote the bytes of its lists back to back (`stream`); the host lists (in list order, each with the
 // stream offset its bytes belong at) are finished here and spliced in.
 bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
-                      View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads)
+                      View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads,
+                      const StreamArrival *arrival)
 {
     ByteBuf hb;
     std::vector<size_t> marks;
@@ -337,27 +338,48 @@ bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> 
     const size_t total = stream.size() + hb.size();
     if (!out.reserve_uninit(total + 16)) return false;
     out.n = total;
-    struct Piece { const uint8_t *src; size_t dst, n; };
+    // the stream arrives in steps; a piece is copied once the stream bytes it reads are there (need), host pieces at once
+    std::vector<size_t> upto;
+    if (arrival) upto = arrival->upto;
+    if (upto.empty() || upto.back() != stream.size()) upto.push_back(stream.size());
+    struct Piece { const uint8_t *src; size_t dst, n, need; };
     std::vector<Piece> pieces;
     const size_t chunk = 1u << 18;
-    auto add = [&](const uint8_t *src, size_t dst, size_t n) {
-        for (size_t o = 0; o < n; o += chunk) pieces.push_back({src + o, dst + o, std::min(chunk, n - o)});
+    size_t step = 0;
+    auto add_host = [&](const uint8_t *src, size_t dst, size_t n) {
+        for (size_t o = 0; o < n; o += chunk) pieces.push_back({src + o, dst + o, std::min(chunk, n - o), 0});
+    };
+    auto add_stream = [&](size_t from, size_t dst, size_t n) {           // stream bytes from .. from+n, cut at the arrival steps
+        while (n) {
+            while (from >= upto[step]) step++;
+            const size_t m = std::min(std::min(chunk, n), upto[step] - from);
+            pieces.push_back({stream.p + from, dst, m, from + m});
+            from += m; dst += m; n -= m;
+        }
     };
     size_t s_at = 0, d_at = 0;
     for (size_t i = 0; i < hnodes.size(); i++) {
         const size_t so = (size_t)hnodes[i].stream_off;
-        if (so > s_at) { add(stream.p + s_at, d_at, so - s_at); d_at += so - s_at; s_at = so; }
+        if (so > s_at) { add_stream(s_at, d_at, so - s_at); d_at += so - s_at; s_at = so; }
         const size_t hn = marks[i + 1] - marks[i];
-        if (hn) { add(hb.p + marks[i], d_at, hn); d_at += hn; }
+        if (hn) { add_host(hb.p + marks[i], d_at, hn); d_at += hn; }
     }
-    if (stream.size() > s_at) add(stream.p + s_at, d_at, stream.size() - s_at);
+    if (stream.size() > s_at) add_stream(s_at, d_at, stream.size() - s_at);
     int T = n_threads < 1 ? 1 : n_threads;
     if (total < (4u << 20)) T = 1;
-    std::vector<std::thread> th;
-    auto work = [&](int t) { for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)T) memcpy(out.p + pieces[i].dst, pieces[i].src, pieces[i].n); };
-    for (int t = 1; t < T; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
+    size_t lo = 0;
+    for (size_t c = 0; c < upto.size(); c++) {
+        if (arrival && arrival->wait && !arrival->wait(c)) return false;
+        size_t hi = lo;
+        while (hi < pieces.size() && pieces[hi].need <= upto[c]) hi++;
+        const int Tc = (hi - lo) < 8 ? 1 : T;
+        auto work = [&](int t) { for (size_t i = lo + (size_t)t; i < hi; i += (size_t)Tc) memcpy(out.p + pieces[i].dst, pieces[i].src, pieces[i].n); };
+        std::vector<std::thread> th;
+        for (int t = 1; t < Tc; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        lo = hi;
+    }
     return true;
 }
 

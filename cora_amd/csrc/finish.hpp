@@ -4,6 +4,7 @@
 // HTS = /root/reference/homTable_setup.cpp.
 #pragma once
 #include <stdint.h>
+#include <functional>
 #include <vector>
 
 namespace cora {
@@ -73,7 +74,15 @@ struct FinishStats { uint64_t exact_nodes = 0, inexact_nodes = 0, dirty_nodes = 
 bool serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<uint64_t> packed,
                        ByteBuf &out, FinishStats &st, int n_threads, std::vector<size_t> *marks = nullptr);
 // Splices the host-finished lists into the byte stream the device wrote (stages.hip, st_items_finish).
+// arrival (optional): the stream is still on its way from the device; wait(c) returns once its first upto[c] bytes are in
+// host memory (upto ascending, the last one = stream.size()).  The host lists are serialised first -- that needs none of
+// the stream -- and each part of the stream is moved to its place as soon as it is there.
+struct StreamArrival {
+    std::vector<size_t> upto;
+    std::function<bool(size_t)> wait;      // false: the copy failed
+};
 bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> hnodes, const InexactDeviceResult &host_items,
-                      View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads);
+                      View<uint64_t> packed, uint64_t device_nodes, ByteBuf &out, FinishStats &st, int n_threads,
+                      const StreamArrival *arrival = nullptr);
 
 }  // namespace cora

@@ -188,6 +188,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         HIPQ(hipEventRecord(job->ev_copy[4], s));
         HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[4], 0));
         HIPQ(hipMemcpyAsync(job->h_packed.p, job->pk.p, (dp.n_words + 4) * sizeof(u64), hipMemcpyDeviceToHost, job->copy_stream));
+        HIPQ(hipEventRecord(job->ev_copy[9], job->copy_stream));
         job->packed_in_flight = true;
     }
     ExactLocal x;

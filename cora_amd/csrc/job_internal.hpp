@@ -146,7 +146,7 @@ struct cora_hip_job {
     // Copies to the host that run beside the kernels (their own stream): the packed reference, which the host part of
     // <Inexact> reads, leaves right after k_pack; the <Inexact> byte stream leaves in pieces while k_node_write writes the rest.
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copy[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_copy[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0-3 piece written, 4 packed, 5-8 piece arrived, 9 packed reference arrived
     bool packed_in_flight = false;        // h_packed is being filled (or is full) for this run
     bool have_ref = false;
     uint64_t genome_bases = 0;

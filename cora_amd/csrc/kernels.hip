@@ -1602,12 +1602,15 @@ __global__ __launch_bounds__(256) void k_node_write(DevParams p, int cw, const u
                                                     const u32 *__restrict__ size, const u64 *__restrict__ off, const u32 *__restrict__ hflag,
                                                     const u64 *__restrict__ hidx, const u64 *__restrict__ hoff, const u32 *__restrict__ node_tie,
                                                     u8 *__restrict__ stream, HostNode *__restrict__ hnodes, u64 *__restrict__ h_key,
-                                                    u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen, u32 *__restrict__ ord, u32 node_lo)
+                                                    u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen, u32 *__restrict__ ord, u32 node_lo,
+                                                    int which /* 1: the lists the host finishes, 2: the others, 3: all */)
 {
     const u32 nd = node_lo + blockIdx.x * 256 + threadIdx.x;           // lists node_lo .. n_nodes-1
     if (nd >= n_nodes) return;
+    const bool for_host = hflag[nd] != 0;
+    if (!(which & (for_host ? 1 : 2))) return;
     const u32 a = node_start[nd], b = node_start[nd + 1];
-    if (hflag[nd]) {
+    if (for_host) {
         HostNode h;
         h.node = nd; h.count = b - a; h.tie = node_tie[nd]; h.reserved = 0;
         h.stream_off = off[nd]; h.item_off = hoff[nd];
@@ -1818,10 +1821,11 @@ void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node
 }
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 node_lo, u32 node_hi, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
-                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen, u32 *ord)
+                       const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen, u32 *ord,
+                       int which)
 {
     if (node_hi > node_lo) hipLaunchKernelGGL(k_node_write, grid_for(node_hi - node_lo), dim3(256), 0, s, p, cw, item_key, item_meta, blen, node_start,
-                                              node_hi, size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen, ord, node_lo);
+                                              node_hi, size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen, ord, node_lo, which);
 }
 
 void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr)

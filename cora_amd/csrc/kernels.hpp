@@ -131,7 +131,8 @@ void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 node_lo, u32 node_hi /* lists node_lo .. node_hi-1 */, const u32 *size, const u64 *off,
                        const u32 *hflag, const u64 *hidx, const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen,
-                       u32 *ord /* [items] scratch of the lists above 16 items */);
+                       u32 *ord /* [items] scratch of the lists above 16 items */,
+                       int which /* 1: only the lists the host finishes (hflag), 2: only the others, 3: all */);
 void launch_test_list_sort(hipStream_t s, u32 *e, u64 n, long forced_depth);
 
 }  // namespace cora

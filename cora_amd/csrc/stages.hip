@@ -320,6 +320,8 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
     View<u8> stream_host;
     View<HostNode> hnodes_host;
     u64 device_nodes = 0, big_nodes = 0;
+    StreamArrival arrival;
+    bool have_arrival = false;
     static const u32 zero_node = 0;
     if (M >= (1ull << 32)) return fail(19, "too many directed items (%llu)", (unsigned long long)M);
     job->stats.inexact_items = M;
@@ -394,23 +396,13 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         RCQ(stream.alloc(totals[0])); RCQ(hnodes.alloc(totals[1])); RCQ(hk.alloc(totals[2])); RCQ(hm.alloc(totals[2])); RCQ(hbl.alloc(totals[2]));
         RCQ(job->h_stream.reserve(totals[0]));
         stream_host.p = job->h_stream.p; stream_host.n = totals[0];
-        for (int c = 0; c < pieces; c++) {
-            launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, piece_node[c], piece_node[c + 1], nsize.p, noff.p, hflag.p, hidx.p, hoff.p,
-                              node_tie.p, stream.p, hnodes.p, hk.p, hm.p, hbl.p, ord.p);
-            // a piece leaves on the copy stream as soon as it is written, while the next one is being written (PCIe at
-            // 55 GB/s takes longer over the whole stream than k_node_write does)
-            HIPQ(hipEventRecord(job->ev_copy[c], s));
-            HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[c], 0));
-            if (piece_off[c + 1] > piece_off[c])
-                HIPQ(hipMemcpyAsync(job->h_stream.p + piece_off[c], stream.p + piece_off[c], piece_off[c + 1] - piece_off[c], hipMemcpyDeviceToHost,
-                                    job->copy_stream));
-        }
-        HIPQ(hipGetLastError());
-        // Wait for the kernels BEFORE queueing the small copies to the host on the main stream.  Queued behind pending
-        // kernels, such copies made the second run of every job 5.5 ms slower (once: a runtime-internal set-up on that
-        // path; bisected with CORA_SYNC_MASK).  The copies need the kernels' results anyway, so the wait costs nothing.
+        // 1. the lists the host finishes: their items leave first (a few MB), so that the host can work on them while
+        //    the device writes the others
+        launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, 0, nn, nsize.p, noff.p, hflag.p, hidx.p, hoff.p, node_tie.p, stream.p,
+                          hnodes.p, hk.p, hm.p, hbl.p, ord.p, 1);
+        // (wait for the kernel BEFORE queueing copies to the host on this stream: queued behind pending kernels such copies
+        //  made the second run of every job 5.5 ms slower -- once, a runtime-internal set-up; bisected with CORA_SYNC_MASK)
         HIPQ(hipStreamSynchronize(s));
-        trace_mark(job, "items: write bytes", 6);
         RCQ(d2h(job, job->h_hnodes, hnodes_host, (const HostNode *)hnodes.p, totals[1]));
         RCQ(d2h(job, job->h_key, ir.key, (const u64 *)hk.p, totals[2]));
         RCQ(d2h(job, job->h_meta, ir.meta, (const u32 *)hm.p, totals[2]));
@@ -423,8 +415,26 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
             else RCQ(d2h(job, job->h_packed, packed_host, (const u64 *)job->pk.p, dp.n_words + 4));
         }
         HIPQ(hipStreamSynchronize(s));
-        HIPQ(hipStreamSynchronize(job->copy_stream));
-        trace_mark(job, "items: copies to host", 7);
+        // 2. the byte stream of all other lists, written and sent in pieces: a piece leaves on the copy stream as soon as it
+        //    is written, while the next one is being written (PCIe at 55 GB/s takes longer over the whole stream than
+        //    k_node_write does); the host moves each piece to its place when it has arrived (assemble_inexact below)
+        arrival.upto.clear();
+        for (int c = 0; c < pieces; c++) {
+            launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, piece_node[c], piece_node[c + 1], nsize.p, noff.p, hflag.p, hidx.p, hoff.p,
+                              node_tie.p, stream.p, hnodes.p, hk.p, hm.p, hbl.p, ord.p, 2);
+            HIPQ(hipEventRecord(job->ev_copy[c], s));
+            HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[c], 0));
+            if (piece_off[c + 1] > piece_off[c])
+                HIPQ(hipMemcpyAsync(job->h_stream.p + piece_off[c], stream.p + piece_off[c], piece_off[c + 1] - piece_off[c], hipMemcpyDeviceToHost,
+                                    job->copy_stream));
+            HIPQ(hipEventRecord(job->ev_copy[5 + c], job->copy_stream));
+            arrival.upto.push_back((size_t)piece_off[c + 1]);
+        }
+        HIPQ(hipGetLastError());
+        arrival.wait = [job](size_t c) { return hipEventSynchronize(job->ev_copy[5 + c]) == hipSuccess; };
+        have_arrival = true;
+        if (packed_host.n && job->packed_in_flight) HIPQ(hipEventSynchronize(job->ev_copy[9]));      // (sent 0.7 s ago)
+        trace_mark(job, "items: copies queued", 7);
         // list starts of the compacted host items
         RCQ(job->h_node_start.reserve(totals[1] + 1));
         for (u64 i = 0; i < totals[1]; i++) job->h_node_start.p[i] = (u32)hnodes_host[i].item_off;
@@ -434,10 +444,12 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         ir.node_start.p = &zero_node; ir.node_start.n = 1;
     }
     HIPQ(hipEventRecord(job->ev[4], s));
-    HIPQ(hipStreamSynchronize(s));
     const auto h0 = std::chrono::steady_clock::now();
-    if (!assemble_inexact(job->hg, stream_host, hnodes_host, ir, packed_host, device_nodes, job->inexact_bytes, fst, job->host_threads))
-        return fail(101, "host allocation for the %zu bytes of <Inexact> failed", stream_host.size());
+    const bool assembled = assemble_inexact(job->hg, stream_host, hnodes_host, ir, packed_host, device_nodes, job->inexact_bytes, fst,
+                                            job->host_threads, have_arrival ? &arrival : nullptr);
+    HIPQ(hipStreamSynchronize(s));
+    HIPQ(hipStreamSynchronize(job->copy_stream));             // (also when the assembly gave up half-way: nothing may stay in flight)
+    if (!assembled) return fail(101, "host allocation for the %zu bytes of <Inexact> failed, or a copy from the device did", stream_host.size());
     fst.big_nodes = big_nodes;                           // lists above 16 items, counted on the device (most never reach the host)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     host_ms += ms;
