@@ -462,6 +462,74 @@ __global__ __launch_bounds__(CT) void k_group_emit(const u64 *__restrict__ key, 
     oval[o] = (u32)g;
 }
 
+// ------------------------------------------------------------------ the order after the table has grown
+// The reference's table re-buckets itself as it fills (collapse_host.cpp: cora_hip_collapse_table_growth).  tr1's
+// _M_rehash walks the old buckets in ascending order, each from head to tail, and pushes every node at the HEAD of its
+// new bucket; a new element goes to the head of its bucket.  With S(k) the iteration order while the table has its
+// k-th bucket count B(k):
+//     S(k) = stable sort by (hash mod B(k)) of  [ elements inserted under B(k), latest first ]  ++  reverse(S(k-1)).
+// The relative order of two elements depends on those two alone, so only the printed groups go through this.
+// An element's number in the insertion order (over distinct read-mers) comes from a bitmap over the ids: a group's first
+// record is its insertion; elements before it = set bits below its id.
+constexpr int MAX_GROWTH = 40;      // (rehash(1) reaches 2^32 elements in 33 steps)
+struct Growth { u64 at[MAX_GROWTH], buckets[MAX_GROWTH]; int n; };
+
+__global__ __launch_bounds__(CT) void k_mark_first(const u32 *__restrict__ id, const u32 *__restrict__ gstart, u64 n_groups, u32 *__restrict__ bm)
+{
+    const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
+    if (g >= n_groups) return;
+    const u32 i = id[gstart[g]];
+    atomicOr(&bm[i >> 5], 1u << (i & 31));
+}
+__global__ __launch_bounds__(CT) void k_word_popc(const u32 *__restrict__ bm, u64 n_words, u32 *__restrict__ cnt)
+{
+    const u64 w = (u64)blockIdx.x * CT + threadIdx.x;
+    if (w < n_words) cnt[w] = (u32)__popc(bm[w]);
+}
+// printed group -> (generation << 32 | ~(element number - 1)) : ascending = generation by generation, latest element first
+__global__ __launch_bounds__(CT) void k_growth_keys(const u32 *__restrict__ id, const u32 *__restrict__ gstart, const u32 *__restrict__ flag,
+                                                    const u64 *__restrict__ oex, u64 n_groups, const u32 *__restrict__ bm,
+                                                    const u64 *__restrict__ wex, Growth gr, u64 *__restrict__ okey, u32 *__restrict__ oval)
+{
+    const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
+    if (g >= n_groups || !flag[g]) return;
+    const u32 i = id[gstart[g]];
+    const u64 element = wex[i >> 5] + (u64)__popc(bm[i >> 5] & ((1u << (i & 31)) - 1u)) + 1;      // 1-based
+    u32 gen = 0;
+    for (int k = 1; k < gr.n; k++) if (gr.at[k] <= element) gen = (u32)k;
+    const u64 o = oex[g];
+    okey[o] = ((u64)gen << 32) | (u64)(0xFFFFFFFFu - (u32)(element - 1));
+    oval[o] = (u32)g;
+}
+__global__ __launch_bounds__(CT) void k_gen_starts(const u64 *__restrict__ key, u64 m, u32 *__restrict__ start /* [MAX_GROWTH], preset to 0xFFFFFFFF */)
+{
+    const u64 i = (u64)blockIdx.x * CT + threadIdx.x;
+    if (i >= m) return;
+    const u32 g = (u32)(key[i] >> 32);
+    if (i == 0 || (u32)(key[i - 1] >> 32) != g) start[g] = (u32)i;
+}
+__global__ __launch_bounds__(CT) void k_gather_hash(const u64 *__restrict__ key, const u32 *__restrict__ gstart, const u32 *__restrict__ grp, u64 m,
+                                                    u64 *__restrict__ hs)
+{
+    const u64 i = (u64)blockIdx.x * CT + threadIdx.x;
+    if (i < m) hs[i] = key[gstart[grp[i]]];
+}
+// the sequence a growth step sorts: the newcomers (a range of the generation-sorted list), then the order so far, reversed
+__global__ __launch_bounds__(CT) void k_level_build(const u64 *__restrict__ hs, u64 B, u32 new_lo, u32 n_new, const u32 *__restrict__ prev, u32 n_prev,
+                                                    u64 *__restrict__ okey, u32 *__restrict__ oval)
+{
+    const u64 j = (u64)blockIdx.x * CT + threadIdx.x;
+    if (j >= (u64)n_new + n_prev) return;
+    const u32 e = j < n_new ? new_lo + (u32)j : prev[n_prev - 1 - (u32)(j - n_new)];
+    okey[j] = hs[e] % B;
+    oval[j] = e;
+}
+__global__ __launch_bounds__(CT) void k_take(const u32 *__restrict__ from, const u32 *__restrict__ idx, u64 m, u32 *__restrict__ out)
+{
+    const u64 i = (u64)blockIdx.x * CT + threadIdx.x;
+    if (i < m) out[i] = from[idx[i]];
+}
+
 // ------------------------------------------------------------------ text of the three files
 struct OutParams {
     u32 D, mapper, n_contigs;      // mapper: 0 GENERIC, 1 BWA, 2 BWA_MEM, 3 BOWTIE_2
@@ -699,6 +767,7 @@ struct cora_hip_collapse {
     cora_hip_collapse_params prm;
     u32 R = 0;
     u64 B = 0, first_rehash_at = 0;
+    Growth growth = {};                       // the table's bucket counts and the element numbers at which it grows
     hipStream_t stream = nullptr;
     cora_hip_job *ref_job = nullptr;          // holds the packed reference (pk, bad, contig table)
     std::vector<u8> h_rd;                     // FASTQ images, 16-byte aligned starts
@@ -856,13 +925,16 @@ int run_impl(cora_hip_collapse *c)
         HIPQ(hipStreamSynchronize(s));
     }
     st.distinct = n_groups;
-    // the reference's table re-buckets itself with its first_rehash_at-th element; the order after that is not reproduced
-    // (windows with letters other than A C G T N enter its table under cut keys: counted here as one element each, an upper bound)
+    // The reference's table re-buckets itself with its first_rehash_at-th element, and again later (Growth): from then on the
+    // order needs every element's number in the insertion order.  Windows with letters other than A C G T N are elements of
+    // that table too (under cut keys, never printed): their exact number and places are not derived here, so a run in which
+    // they could decide on which side of a growth step an element falls is refused.
     const u64 garbage_bound = other_letters * R;
-    if (n_groups + garbage_bound + 1 >= c->first_rehash_at)
-        return fail(77, "%llu distinct read-mers (+ %llu reference windows with other letters): the reference's hash map re-buckets itself at %llu "
-                        "elements and its output order beyond that point is not reproduced", (unsigned long long)n_groups,
-                    (unsigned long long)garbage_bound, (unsigned long long)c->first_rehash_at);
+    const bool grown = n_groups + garbage_bound + 1 >= c->first_rehash_at;
+    if (grown && garbage_bound)
+        return fail(77, "%llu distinct read-mers + up to %llu reference windows with letters other than A C G T N: the reference's hash map "
+                        "re-buckets itself at %llu elements, and where those windows fall in its insertion order is not reproduced",
+                    (unsigned long long)n_groups, (unsigned long long)garbage_bound, (unsigned long long)c->first_rehash_at);
     RCQ(gstart.alloc(n_groups + 1));
     hipLaunchKernelGGL(k_group_starts, dim3(grid_of(N, CT)), dim3(CT), 0, s, head.p, gex.p, N, gstart.p, n_groups);
     head.release(); gex.release();
@@ -881,16 +953,69 @@ int run_impl(cora_hip_collapse *c)
     }
     st.printed = M;
     DBuf<u64> okey, tokey;
-    DBuf<u32> oval, toval;
+    DBuf<u32> oval, toval, grown_ord;
     RCQ(okey.alloc(M + 1)); RCQ(tokey.alloc(M + 1)); RCQ(oval.alloc(M + 1)); RCQ(toval.alloc(M + 1));
-    if (M) hipLaunchKernelGGL(k_group_emit, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, skey, sid, gstart.p, gflag.p, oex.p, n_groups, c->B, okey.p, oval.p);
-    gflag.release(); oex.release();
     SortArrays oa, ot;
     oa.a = okey.p; oa.c = oval.p; ot.a = tokey.p; ot.c = toval.p;
-    int bucket_bits = 1;
-    while ((1ull << bucket_bits) < c->B) bucket_bits++;
-    if (M && radix_sort(s, oa, ot, M, 0, 32 + bucket_bits, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
-    const u32 *ord = oa.c;
+    const u32 *ord = nullptr;
+    st.table_growth_steps = 0;
+    if (!grown) {
+        if (M) hipLaunchKernelGGL(k_group_emit, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, skey, sid, gstart.p, gflag.p, oex.p, n_groups, c->B, okey.p, oval.p);
+        gflag.release(); oex.release();
+        int bucket_bits = 1;
+        while ((1ull << bucket_bits) < c->B) bucket_bits++;
+        if (M && radix_sort(s, oa, ot, M, 0, 32 + bucket_bits, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
+        ord = oa.c;
+    } else {
+        // ---- the table grew (see k_mark_first ...): element numbers, generations, then one stable sort per bucket count ----
+        const Growth &gr = c->growth;
+        int g_last = 0;
+        for (int k = 1; k < gr.n; k++) if (gr.at[k] <= n_groups) g_last = k;
+        st.table_growth_steps = (u32)g_last;
+        const u64 id_words = (std::min<u64>((u64)G + N, 1ull << 32) + 31) / 32 + 1;    // ids: reference positions below G, then G + read-mer index
+        DBuf<u32> bm, wcnt, gen_start;
+        DBuf<u64> wex, hs;
+        RCQ(bm.alloc(id_words)); RCQ(wcnt.alloc(id_words)); RCQ(wex.alloc(id_words + 1)); RCQ(gen_start.alloc(MAX_GROWTH)); RCQ(hs.alloc(M + 1));
+        RCQ(grown_ord.alloc(M + 1));
+        HIPQ(hipMemsetAsync(bm.p, 0, id_words * sizeof(u32), s));
+        hipLaunchKernelGGL(k_mark_first, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, sid, gstart.p, n_groups, bm.p);
+        hipLaunchKernelGGL(k_word_popc, dim3(grid_of(id_words, CT)), dim3(CT), 0, s, bm.p, id_words, wcnt.p);
+        RCQ(scan_u32(s, wcnt.p, wex.p, id_words, tot.p));
+        if (M) hipLaunchKernelGGL(k_growth_keys, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, sid, gstart.p, gflag.p, oex.p, n_groups, bm.p, wex.p, gr, okey.p, oval.p);
+        gflag.release(); oex.release(); wcnt.release();
+        if (M && radix_sort(s, oa, ot, M, 0, 40, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
+        // oa: printed groups, generation by generation, latest element first; where each generation starts
+        u32 h_start[MAX_GROWTH + 1];
+        HIPQ(hipMemsetAsync(gen_start.p, 0xFF, MAX_GROWTH * sizeof(u32), s));
+        if (M) hipLaunchKernelGGL(k_gen_starts, dim3(grid_of(M, CT)), dim3(CT), 0, s, oa.a, M, gen_start.p);
+        HIPQ(hipMemcpyAsync(h_start, gen_start.p, MAX_GROWTH * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        h_start[MAX_GROWTH] = (u32)M;
+        for (int k = MAX_GROWTH - 1; k >= 0; k--) if (h_start[k] == 0xFFFFFFFFu) h_start[k] = h_start[k + 1];       // a generation without printed groups
+        if (M) hipLaunchKernelGGL(k_gather_hash, dim3(grid_of(M, CT)), dim3(CT), 0, s, skey, gstart.p, oa.c, M, hs.p);
+        // the generation-sorted group list stays where it is (gen_grp); the levels sort indices into it
+        DBuf<u32> gen_grp, lv_a, lv_b, cur;
+        DBuf<u64> lk_a, lk_b;
+        RCQ(gen_grp.alloc(M + 1)); RCQ(lv_a.alloc(M + 1)); RCQ(lv_b.alloc(M + 1)); RCQ(cur.alloc(M + 1)); RCQ(lk_a.alloc(M + 1)); RCQ(lk_b.alloc(M + 1));
+        if (M) HIPQ(hipMemcpyAsync(gen_grp.p, oa.c, M * sizeof(u32), hipMemcpyDeviceToDevice, s));
+        u32 n_cur = 0;
+        for (int k = 0; k <= g_last && M; k++) {
+            const u32 new_lo = h_start[k], n_new = h_start[k + 1] - h_start[k];
+            const u64 n = (u64)n_new + n_cur;
+            if (!n) continue;
+            hipLaunchKernelGGL(k_level_build, dim3(grid_of(n, CT)), dim3(CT), 0, s, hs.p, gr.buckets[k], new_lo, n_new, cur.p, n_cur, lk_a.p, lv_a.p);
+            SortArrays la, lb;
+            la.a = lk_a.p; la.c = lv_a.p; lb.a = lk_b.p; lb.c = lv_b.p;
+            int bits = 1;
+            while ((1ull << bits) < gr.buckets[k]) bits++;
+            if (radix_sort(s, la, lb, n, 0, bits, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
+            HIPQ(hipMemcpyAsync(cur.p, la.c, n * sizeof(u32), hipMemcpyDeviceToDevice, s));
+            n_cur = (u32)n;
+        }
+        if (M) hipLaunchKernelGGL(k_take, dim3(grid_of(M, CT)), dim3(CT), 0, s, gen_grp.p, cur.p, M, grown_ord.p);
+        HIPQ(hipStreamSynchronize(s));
+        ord = grown_ord.p;
+    }
     HIPQ(hipEventRecord(ev[4], s));
 
     // ---- sizes, places, bytes ----
@@ -958,7 +1083,18 @@ int cora_hip_collapse_create(const cora_hip_collapse_params *p, cora_hip_collaps
     cora_hip_collapse *c = new cora_hip_collapse();
     c->prm = *p;
     c->R = (u32)(p->read_len / p->splits);                                                              // CL:566-583
-    if (cora_hip_collapse_table_geometry(&c->B, &c->first_rehash_at) || c->B < 2) { delete c; return fail(19, "cannot determine the hash table geometry"); }
+    {
+        // the table as the reference sets it up (CL:640-643: rehash(200000000)); CORA_COLLAPSE_TABLE_REQUEST makes it small, so
+        // that tests reach the growth steps with a few thousand read-mers
+        u64 request = 200000000ull;
+        if (const char *e = getenv("CORA_COLLAPSE_TABLE_REQUEST")) { const long long v = atoll(e); if (v >= 1) request = (u64)v; }
+        uint64_t at[MAX_GROWTH], bk[MAX_GROWTH];
+        const int n = cora_hip_collapse_table_growth(request, 1ull << 32, at, bk, MAX_GROWTH);
+        if (n < 2 || bk[0] < 2 || at[n - 1] < (1ull << 32)) { delete c; return fail(19, "cannot determine the hash table's growth (%d steps)", n); }
+        c->growth.n = n;
+        for (int k = 0; k < n; k++) { c->growth.at[k] = at[k]; c->growth.buckets[k] = bk[k]; }
+        c->B = bk[0]; c->first_rehash_at = at[1];
+    }
     memset(&c->st, 0, sizeof c->st);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(100, "hipStreamCreate failed"); }
     *out = c;

@@ -28,7 +28,7 @@ EXPORTS = [
     "cora_hip_tables_export", "cora_hip_tables_lookup_equiv", "cora_hip_tables_destroy",
     "cora_hip_fasta_scan", "cora_hip_fasta_get_info", "cora_hip_fasta_fai_text", "cora_hip_fasta_contig",
     "cora_hip_fasta_destroy", "cora_hip_job_set_reference_fasta",
-    "cora_hip_collapse_table_geometry", "cora_hip_collapse_create", "cora_hip_collapse_set_reference", "cora_hip_collapse_set_fragment", "cora_hip_collapse_set_lrn_offset", "cora_hip_collapse_add_reads", "cora_hip_collapse_add_reads_device",
+    "cora_hip_collapse_table_geometry", "cora_hip_collapse_table_growth", "cora_hip_collapse_create", "cora_hip_collapse_set_reference", "cora_hip_collapse_set_fragment", "cora_hip_collapse_set_lrn_offset", "cora_hip_collapse_add_reads", "cora_hip_collapse_add_reads_device",
     "cora_hip_collapse_run", "cora_hip_collapse_outputs", "cora_hip_collapse_get_stats", "cora_hip_collapse_destroy",
     "cora_hip_fqsplit_parse_signals", "cora_hip_fqsplit_create", "cora_hip_fqsplit_add_reads", "cora_hip_fqsplit_run",
     "cora_hip_fqsplit_group", "cora_hip_fqsplit_group_device", "cora_hip_fqsplit_set_device_only", "cora_hip_fqsplit_get_stats", "cora_hip_fqsplit_destroy",
@@ -84,7 +84,7 @@ class CollapseStats(C.Structure):
         "reads", "read_mers", "ref_windows", "distinct", "printed", "lrn_names", "hash_collisions", "reads_bytes",
         "perfect_bytes", "lrn_bytes")] + [(n, C.c_float) for n in (
         "ms_parse", "ms_keys", "ms_group", "ms_order", "ms_text", "ms_device", "ms_total", "ms_sort_scatter")] + [
-        ("n_sort_scatter", C.c_uint32), ("sort_scatter_bytes", C.c_uint64)]
+        ("n_sort_scatter", C.c_uint32), ("sort_scatter_bytes", C.c_uint64), ("table_growth_steps", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -274,13 +274,20 @@ typedef struct cora_hip_collapse_stats {
     float ms_sort_scatter;     /* time inside the radix scatter launches of this run */
     uint32_t n_sort_scatter;
     uint64_t sort_scatter_bytes;
+    uint32_t table_growth_steps;   /* how often the reference's hash map would have re-bucketed itself during this run (0: below 182 356 234 read-mers) */
+    uint32_t reserved0;
 } cora_hip_collapse_stats;
 
 /* Bucket count of the reference's std::tr1::unordered_map after max_load_factor(1 / 1.13) and rehash(200000000)
- * (CL:640-643) and the number of the element whose insertion makes it re-bucket itself, both asked of libstdc++'s own
- * rehash policy at run time.  The output order follows from the first; runs that would reach the second are refused
- * (status 77): the order after a re-bucketing is not reproduced. */
+ * (CL:640-643) and the number of the element whose insertion makes it re-bucket itself for the first time, both asked of
+ * libstdc++'s own rehash policy at run time.  The output order follows from the bucket counts; runs that pass the second
+ * number are ordered through the table's whole growth history (cora_hip_collapse_table_growth). */
 int cora_hip_collapse_table_geometry(uint64_t *buckets, uint64_t *first_rehash_at);
+/* The growth history of that table for rehash(request) (the reference: 200000000): buckets[0] = the initial bucket count
+ * (at[0] = 0); for k >= 1, at[k] = the number (1-based, over distinct keys in insertion order) of the element whose
+ * insertion makes the table re-bucket itself first, to buckets[k] buckets.  Asked of libstdc++'s own rehash policy.
+ * Returns the number of entries (at most cap), ending with the first one beyond max_elements. */
+int cora_hip_collapse_table_growth(uint64_t request, uint64_t max_elements, uint64_t *at, uint64_t *buckets, int cap);
 int cora_hip_collapse_create(const cora_hip_collapse_params *params, cora_hip_collapse **out);
 /* The reference (argv[4]; leave out for NOREF): a scanned FASTA.  The .fai and the line length (argv[5]) are not needed. */
 int cora_hip_collapse_set_reference(cora_hip_collapse *c, const cora_hip_fasta *reference);

@@ -14,17 +14,28 @@
  * libstdc++'s tr1 hashtable that is: bucket index ascending, and inside a bucket the latest insertion first (nodes are
  * pushed at the bucket's head).  Hash = FNV-1a 64 over the key's bytes (tr1::hash<string>), bucket = hash mod B with
  * B = 206062531 = the table's bucket count after max_load_factor(1/1.13) and rehash(200000000) (CL:641-643;
- * measured on the real container, see tests/test_collapse_oracle.py::test_hashtable_constants).  The table's first
- * rehash comes with its 182356234th element; this restatement stops with status 77 before that point instead of
- * reproducing the re-bucketing order ("parity unpinned" beyond it: no run of the reference that large fits here).
+ * measured on the real container, see tests/test_collapse_oracle.py::test_hashtable_constants).
+ *
+ * The table GROWS: with its 182356234th element it re-buckets itself (then at 370310930, 751990753, ... elements; the
+ * history is libstdc++'s rehash policy's and comes from cora_hip_collapse_table_growth, pinned against the real container
+ * by tests/test_collapse_growth.py; CORA_COLLAPSE_GROWTH="at:buckets,..." replaces the built-in history of
+ * rehash(200000000) so that tests reach the growth steps with small inputs).  tr1's _M_rehash walks the old buckets in
+ * ascending order, each from head to tail, and pushes every node at the HEAD of its new bucket; a new element is pushed
+ * at the head of its bucket.  So, with S(k) the iteration order while the table has its k-th bucket count B(k):
+ *     S(k) = stable sort by (hash mod B(k)) of [ the elements inserted under B(k), latest first ] ++ reverse(S(k-1))
+ * (order_nodes below).  The model -- not the reference at that size: a run with 1.8e8 distinct read-mers does not fit this
+ * container -- is pinned against the real std::tr1::unordered_map (tests/native/tr1_table_order.cpp) for thousands of
+ * random keys and small initial tables; beyond the first growth step the REFERENCE's own output order is "parity
+ * unpinned".
  *
  * Pinned: tests/golden/collapse_cases/ holds the three output files the REAL reference (oracle/_ref/collapse[_L])
  * wrote for every mode combination (tests/golden/make_collapse_golden.py); tests/test_collapse_oracle.py compares.
  *
  * Bytes outside A C G T N: the reference's complement table is zero for them (CL:86-94), so a reference window that holds
  * one (IUPAC letters; the loader only upper-cases, CL:388-400) enters the table under a key that is either cut at the
- * NUL or still holds the letter.  No read-mer over A C G T N can equal such a key, so these windows never reach an output
- * file; they are skipped here and only counted against the first-rehash limit (each as one element, an upper bound).
+ * NUL or still holds the letter (canonical() below follows CL:97-122 byte for byte).  No read-mer over A C G T N can equal
+ * such a key, so these windows never reach an output file, but they are elements of the table: they count towards its
+ * growth and take their place in the insertion order.
  * A READ with such a byte is refused with status 78 (the reference would cut its key).
  *
  *   collapse_oracle <the reference's 16 arguments> [L]         L = collapse_L (-DCHR_SHORT: contig ids up to 65530)
@@ -34,13 +45,16 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define BUCKETS 206062531ULL
-#define FIRST_REHASH_AT 182356234ULL
+/* growth history of the table for rehash(200000000): element number that triggers the step, bucket count from then on */
+static uint64_t g_at[32] = {0, 182356234ULL, 370310930ULL, 751990753ULL, 1527068289ULL, 3101019521ULL, 7601712386ULL};
+static uint64_t g_buckets[32] = {206062531ULL, 418451333ULL, 849749479ULL, 1725587117ULL, 3504151727ULL, 8589934583ULL, 25769803693ULL};
+static int n_growth = 7;            /* (the last entry lies beyond the 2^32 elements this restatement can hold) */
 #define MAXLINE 300                       /* CL:27 */
 
 typedef struct {
     uint64_t hash;          /* FNV-1a 64 of the canonical read-mer */
-    uint32_t key;           /* offset of the canonical read-mer in the pool */
+    uint32_t key;           /* offset of the key in the pool */
+    uint16_t klen;          /* its length: R, or less for the cut key of a window with a byte outside A C G T N */
     uint32_t ref_code;      /* 0 = not in the reference */
     uint32_t ref_pos;
     int8_t ref_dir;         /* -1 = created by a read (CL:953) */
@@ -53,7 +67,6 @@ static char *pool; static size_t pool_len, pool_cap;
 static uint32_t *slots; static size_t n_slots;              /* open addressing, value = node index + 1 */
 static uint64_t *id_val; static uint32_t *id_next; static size_t n_ids, cap_ids;   /* identity lists, 1-based links */
 static int R;                                                /* read-mer length */
-static uint64_t garbage_windows;   /* N-free reference windows with a byte outside A C G T: see the header */
 
 static uint64_t fnv1a(const char *s, int n)
 {
@@ -64,13 +77,19 @@ static uint64_t fnv1a(const char *s, int n)
 
 static char comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N'; } return 0; }
 
-/* CL:97-122: 1 iff the reverse complement is lexicographically smaller; out = the canonical read-mer */
-static int canonical(const char *s, char *out)
+/* CL:97-122: 1 iff the reverse complement is lexicographically smaller; out = the key the table is asked for, *len its
+ * length (R unless the reverse complement was taken and holds a NUL: std::string(char*) stops there) */
+static int canonical(const char *s, char *out, int *len)
 {
+    *len = R;
     for (int i = 0; i < R; i++) {
         char c = comp(s[R - 1 - i]);
         if (s[i] < c) { memcpy(out, s, R); return 0; }
-        if (s[i] > c) { for (int k = 0; k < R; k++) out[k] = comp(s[R - 1 - k]); return 1; }
+        if (s[i] > c) {
+            for (int k = 0; k < R; k++) out[k] = comp(s[R - 1 - k]);
+            for (int k = 0; k < R; k++) if (!out[k]) { *len = k; break; }
+            return 1;
+        }
     }
     memcpy(out, s, R);
     return 0;
@@ -89,24 +108,24 @@ static void grow_slots(void)
 }
 
 /* find or insert; *created says which */
-static node_t *lookup(const char *key, int *created)
+static node_t *lookup(const char *key, int klen, int *created)
 {
     if ((n_nodes + 1) * 2 > n_slots) grow_slots();
-    const uint64_t h = fnv1a(key, R);
+    const uint64_t h = fnv1a(key, klen);
     size_t p = (h * 0x9E3779B97F4A7C15ULL) >> 20 & (n_slots - 1);
     while (slots[p]) {
         node_t *nd = &nodes[slots[p] - 1];
-        if (nd->hash == h && memcmp(pool + nd->key, key, R) == 0) { *created = 0; return nd; }
+        if (nd->hash == h && nd->klen == klen && memcmp(pool + nd->key, key, (size_t)klen) == 0) { *created = 0; return nd; }
         p = (p + 1) & (n_slots - 1);
     }
-    if (n_nodes + garbage_windows + 1 >= FIRST_REHASH_AT) { fprintf(stderr, "more than %llu distinct read-mers: beyond the table's first rehash\n", FIRST_REHASH_AT - 1); exit(77); }
+    if (n_nodes + 1 >= 0xFFFFFFFFull) { fprintf(stderr, "more than 2^32 distinct read-mers\n"); exit(77); }
     if (n_nodes == cap_nodes) { cap_nodes = cap_nodes ? cap_nodes * 2 : 1024; nodes = (node_t *)realloc(nodes, cap_nodes * sizeof(node_t)); }
     if (pool_len + R > pool_cap) { pool_cap = pool_cap ? pool_cap * 2 : (1u << 20); pool = (char *)realloc(pool, pool_cap); }
     if (pool_len + R > 0xFFFFFFFFull) { fprintf(stderr, "key pool above 4 GiB\n"); exit(77); }
     node_t *nd = &nodes[n_nodes];
     memset(nd, 0, sizeof *nd);
-    nd->hash = h; nd->key = (uint32_t)pool_len;
-    memcpy(pool + pool_len, key, R); pool_len += R;
+    nd->hash = h; nd->key = (uint32_t)pool_len; nd->klen = (uint16_t)klen;
+    memcpy(pool + pool_len, key, (size_t)klen); pool_len += (size_t)klen;
     slots[p] = (uint32_t)n_nodes + 1;
     n_nodes++;
     *created = 1;
@@ -152,9 +171,10 @@ static void add_readmer_coded(const char *s, uint64_t code)
 {
     char key[MAXLINE + 1];
     for (int i = 0; i < R; i++) if (!comp(s[i])) bad_byte("a read", s[i]);
-    const int sw = canonical(s, key);
+    int klen;
+    const int sw = canonical(s, key, &klen);
     int created;
-    node_t *nd = lookup(key, &created);
+    node_t *nd = lookup(key, klen, &created);
     int flag = sw;
     if (created) { nd->ref_code = 0; nd->ref_dir = -1; }
     else if (nd->ref_dir != -1) flag = sw != nd->ref_dir;                    /* CL:963-968 */
@@ -166,12 +186,42 @@ static void add_readmer_coded(const char *s, uint64_t code)
     item_index++;
 }
 
-static int cmp_out(const void *a, const void *b)
+/* The table's iteration order over the nodes that are printed (see the header): generation of a node = number of growth
+ * steps that came before its insertion (node i is element i + 1). */
+typedef struct { uint64_t b; uint32_t pos, node; } ord_t;
+static int cmp_ord(const void *a, const void *b)
 {
-    const node_t *x = &nodes[*(const uint32_t *)a], *y = &nodes[*(const uint32_t *)b];
-    const uint64_t bx = x->hash % BUCKETS, by = y->hash % BUCKETS;
-    if (bx != by) return bx < by ? -1 : 1;
-    return x > y ? -1 : 1;                                                   /* later insertion first */
+    const ord_t *x = (const ord_t *)a, *y = (const ord_t *)b;
+    if (x->b != y->b) return x->b < y->b ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);                  /* stable */
+}
+static int generation_of(uint64_t element)
+{
+    int g = 0;
+    while (g + 1 < n_growth && g_at[g + 1] <= element) g++;
+    return g;
+}
+static size_t order_nodes(uint32_t *order)
+{
+    size_t m = 0, total = 0;
+    for (size_t i = 0; i < n_nodes; i++) total += nodes[i].count != 0;
+    ord_t *w = (ord_t *)malloc((total + 1) * sizeof(ord_t));
+    uint32_t *cur = (uint32_t *)malloc((total + 1) * 4);
+    const int g_last = n_nodes ? generation_of((uint64_t)n_nodes) : 0;
+    if (n_nodes && g_last + 1 >= n_growth && g_at[n_growth - 1] <= (uint64_t)n_nodes) { fprintf(stderr, "the growth history ends before element %zu\n", n_nodes); exit(77); }
+    for (int k = 0; k <= g_last; k++) {
+        size_t n = 0;
+        const uint64_t first = k ? g_at[k] : 1, last = (k + 1 < n_growth && g_at[k + 1] - 1 < n_nodes) ? g_at[k + 1] - 1 : n_nodes;   /* elements first .. last */
+        for (uint64_t e = last; e >= first && e >= 1; e--) if (nodes[e - 1].count) { w[n].node = (uint32_t)(e - 1); n++; }   /* latest first */
+        for (size_t j = m; j-- > 0;) { w[n].node = cur[j]; n++; }                                                          /* reverse(S(k-1)) */
+        for (size_t j = 0; j < n; j++) { w[j].pos = (uint32_t)j; w[j].b = nodes[w[j].node].hash % g_buckets[k]; }
+        qsort(w, n, sizeof(ord_t), cmp_ord);
+        for (size_t j = 0; j < n; j++) cur[j] = w[j].node;
+        m = n;
+    }
+    memcpy(order, cur, m * 4);
+    free(w); free(cur);
+    return m;
 }
 
 static char *read_file(const char *path, size_t *n)
@@ -202,6 +252,19 @@ int main(int argc, char **argv)
 {
     if (argc != 17 && !(argc == 18 && strcmp(argv[17], "L") == 0)) { fprintf(stderr, "usage: collapse_oracle <16 arguments of collapse> [L]\n"); return 10; }
     const int chr_short = argc == 18;
+    if (getenv("CORA_COLLAPSE_GROWTH")) {                                    /* "at:buckets,at:buckets,..." (tests: a small table) */
+        const char *e = getenv("CORA_COLLAPSE_GROWTH");
+        n_growth = 0;
+        while (*e && n_growth < 32) {
+            char *end;
+            g_at[n_growth] = strtoull(e, &end, 10);
+            if (*end != ':') break;
+            g_buckets[n_growth] = strtoull(end + 1, &end, 10);
+            n_growth++;
+            e = *end == ',' ? end + 1 : end;
+        }
+        if (n_growth < 1 || g_at[0] != 0) { fprintf(stderr, "bad CORA_COLLAPSE_GROWTH\n"); return 19; }
+    }
     const unsigned invalid_code = chr_short ? 65531u : 251u;                 /* CL:62-66 */
     uint64_t lrn_count = (uint64_t)atoi(argv[16]);
     const int fragmented = strcmp(argv[13], "NONE") != 0;
@@ -258,18 +321,18 @@ int main(int argc, char **argv)
             for (uint32_t i = 1; i <= len[c]; i++) if (q[i] > 'Z') q[i] -= 32;
             if (len[c] < (uint32_t)R) continue;
             const uint32_t lim = len[c] - R + 1;
-            int n_count = 0, other = 0;
-            for (int i = 1; i <= R; i++) { n_count += q[i] == 'N'; other += !comp(q[i]); }
+            int n_count = 0;
+            for (int i = 1; i <= R; i++) n_count += q[i] == 'N';
             for (uint32_t i = 1; i <= lim; i++) {
-                if (n_count == 0 && other) garbage_windows++;
-                if (n_count == 0 && !other && frag_included(q + i)) {       /* CL:712-835: only this group's windows */
-                    const int sw = canonical(q + i, key);
+                if (n_count == 0 && frag_included(q + i)) {                  /* CL:712-835: only this group's windows */
+                    int klen;
+                    const int sw = canonical(q + i, key, &klen);            /* (a window with other letters: see the header) */
                     int created;
-                    node_t *nd = lookup(key, &created);
+                    node_t *nd = lookup(key, klen, &created);
                     if (created) { nd->ref_code = (uint32_t)c; nd->ref_pos = i; nd->ref_dir = (int8_t)sw; }
                 }
-                n_count -= q[i] == 'N'; other -= !comp(q[i]);
-                if (i + R <= len[c]) { n_count += q[i + R] == 'N'; other += !comp(q[i + R]); }
+                n_count -= q[i] == 'N';
+                if (i + R <= len[c]) n_count += q[i + R] == 'N';
             }
             free(q);
         }
@@ -327,9 +390,7 @@ int main(int argc, char **argv)
 
     /* ---- output in the hash map's iteration order (CL:2295-2405) ---- */
     uint32_t *order = (uint32_t *)malloc((n_nodes + 1) * 4);
-    size_t m = 0;
-    for (size_t i = 0; i < n_nodes; i++) if (nodes[i].count) order[m++] = (uint32_t)i;
-    qsort(order, m, 4, cmp_out);
+    const size_t m = order_nodes(order);
     FILE *fr = fopen(argv[3], "w"), *fp = fopen(argv[7], "w"), *fl = fopen(argv[9], "w");
     if (!fr || !fp || !fl) { fprintf(stderr, "cannot open the outputs\n"); return 68; }
     char *name = NULL; size_t name_cap = 0;
@@ -371,6 +432,12 @@ int main(int argc, char **argv)
     fclose(fr); fclose(fp); fclose(fl);
     FILE *fk = fopen(argv[15], "w");
     if (fk) { fputs("Y\n", fk); fclose(fk); }                                 /* CL:2425-2426 */
-    fprintf(stderr, "read-mers %llu  distinct %zu  printed %zu\n", (unsigned long long)item_index, n_nodes, m);
+    size_t n_other = 0;                       /* elements under keys of windows with a byte outside A C G T N (see the header) */
+    for (size_t i = 0; i < n_nodes; i++) {
+        int o = nodes[i].klen != R;
+        for (int k = 0; k < nodes[i].klen && !o; k++) o = !comp(pool[nodes[i].key + k]);
+        n_other += (size_t)o;
+    }
+    fprintf(stderr, "read-mers %llu  distinct %zu  printed %zu  other-letter-keys %zu\n", (unsigned long long)item_index, n_nodes - n_other, m, n_other);
     return 0;
 }

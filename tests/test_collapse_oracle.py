@@ -82,7 +82,7 @@ int main() {
         fnv = ((fnv ^ c) * 1099511628211) & (2 ** 64 - 1)
     assert [int(x) for x in got] == [206062531, fnv, 206062531, 182356234]
     text = open(os.path.join(helpers.ORACLE_DIR, "collapse_oracle.c")).read()
-    assert "#define BUCKETS 206062531ULL" in text and "#define FIRST_REHASH_AT 182356234ULL" in text
+    assert "g_at[32] = {0, 182356234ULL," in text and "g_buckets[32] = {206062531ULL," in text
 
 
 def test_oracle_refuses_what_it_does_not_restate(tmp_path):

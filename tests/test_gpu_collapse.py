@@ -57,6 +57,35 @@ def test_forced_hash_collisions_change_nothing(name, bits, monkeypatch):
     check_outputs(name, outs)
 
 
+@pytest.mark.parametrize("request_", ["1", "100", "3000"])
+@pytest.mark.parametrize("name", sorted(mcg.CASES))
+def test_order_after_the_hash_map_has_grown(name, request_, tmp_path, monkeypatch):
+    """The reference's table re-buckets itself from 182 356 234 read-mers on (a human reference has 2.9e9 windows) and prints
+    in an order that depends on the whole insertion history.  Here the table starts small (CORA_COLLAPSE_TABLE_REQUEST; the
+    oracle gets the same history through CORA_COLLAPSE_GROWTH) and grows up to ten times during each golden case; the
+    oracle's order is pinned against the real container (tests/test_collapse_growth.py).  A reference with letters other
+    than A C G T N is refused once the table would grow (status 77): where its cut keys fall is not derived on the GPU."""
+    from test_collapse_growth import growth_env
+    case = mcg.CASES[name]
+    monkeypatch.setenv("CORA_COLLAPSE_TABLE_REQUEST", request_)
+    monkeypatch.setenv("CORA_COLLAPSE_GROWTH", growth_env(int(request_), 1 << 32))
+    os.makedirs(tmp_path / "o")
+    want, r = mcg.run_case(build_collapse_oracle(), case, str(tmp_path / "o"), extra=(["L"] if case[6] else []))
+    assert r.returncode == 0, r.stderr[-300:]
+    os.makedirs(tmp_path / "g")
+    got, r = mcg.run_case(COLLAPSE_EXE + ("_L" if case[6] else ""), case, str(tmp_path / "g"))
+    ref = case[1]
+    other = 0
+    if ref:
+        text = open(os.path.join(helpers.GOLDEN, "inputs", ref + ".fa")).read()
+        other = sum(1 for ln in text.split("\n") if not ln.startswith(">") for ch in ln.upper() if ch not in "ACGTN")
+    if r.returncode == 77:
+        assert other > 0, r.stdout[-300:]
+        return
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-300:])
+    assert got == want, "%s: files differ from the oracle's after growth" % name
+
+
 @pytest.mark.parametrize("name", ["p_full_generic", "s_half_generic", "multi_s_three", "s_full_bwa_d2"])
 def test_reference_windows_hashed_without_the_n_test(name, monkeypatch):
     """the hashing loop for reference windows that leaves the N test out (a window with an N is
