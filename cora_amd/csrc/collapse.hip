@@ -16,6 +16,9 @@
 // The hash (tr1::hash<string> = FNV-1a 64) and B come from libstdc++ itself on the host (collapse_host.cpp).
 // Integer / byte work; the heavy parts are the sequential FNV over R bases per record (ALU) and the sorts (HBM).
 #include "job_internal.hpp"
+#include <algorithm>
+#include <string>
+#include <unordered_set>
 #include "reads_common.hpp"
 
 using namespace cora;
@@ -486,15 +489,45 @@ __global__ __launch_bounds__(CT) void k_word_popc(const u32 *__restrict__ bm, u6
     const u64 w = (u64)blockIdx.x * CT + threadIdx.x;
     if (w < n_words) cnt[w] = (u32)__popc(bm[w]);
 }
+// Reference bases that are neither A C G T nor N (after upper-casing, CL:388-400), with their places: the windows that hold
+// one enter the reference's table under keys of their own (CL:86-122: the complement table is zero for such a letter), which
+// the host derives from this list (other_letter_elements below).
+struct OtherLetter { u32 g, ch; };
+__global__ __launch_bounds__(CT) void k_other_list(DevParams p, const u8 *__restrict__ raw, const u32 *__restrict__ bad, OtherLetter *__restrict__ out,
+                                                   u32 cap, unsigned long long *__restrict__ n)
+{
+    const u64 w = (u64)blockIdx.x * CT + threadIdx.x;
+    if (w >= p.n_words) return;
+    u32 b = bad[w];
+    while (b) {
+        const int i = __clz((int)b);
+        b &= ~(0x80000000u >> i);
+        const u64 g = (w << 5) + (u64)i;
+        u32 lo = 0, hi = p.n_contigs;
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (p.ctg_gstart[mid] <= g) lo = mid; else hi = mid; }
+        const u64 local = g - p.ctg_gstart[lo];
+        if (local >= p.ctg_len[lo]) continue;                                  // padding between contigs
+        const u64 at = p.ctg_off[lo] + local + local / p.line_width;
+        u32 ch = at < p.image_bytes ? raw[at] : (u32)'N';
+        if (ch > 'Z') ch -= 32;
+        if (ch == 'N') continue;
+        const unsigned long long k = atomicAdd(n, 1ull);
+        if (k < cap) { out[k].g = (u32)g; out[k].ch = ch; }
+    }
+}
+
 // printed group -> (generation << 32 | ~(element number - 1)) : ascending = generation by generation, latest element first
 __global__ __launch_bounds__(CT) void k_growth_keys(const u32 *__restrict__ id, const u32 *__restrict__ gstart, const u32 *__restrict__ flag,
                                                     const u64 *__restrict__ oex, u64 n_groups, const u32 *__restrict__ bm,
-                                                    const u64 *__restrict__ wex, Growth gr, u64 *__restrict__ okey, u32 *__restrict__ oval)
+                                                    const u64 *__restrict__ wex, const u32 *__restrict__ other_ids, u32 n_other, Growth gr,
+                                                    u64 *__restrict__ okey, u32 *__restrict__ oval)
 {
     const u64 g = (u64)blockIdx.x * CT + threadIdx.x;
     if (g >= n_groups || !flag[g]) return;
     const u32 i = id[gstart[g]];
-    const u64 element = wex[i >> 5] + (u64)__popc(bm[i >> 5] & ((1u << (i & 31)) - 1u)) + 1;      // 1-based
+    u32 lo = 0, hi = n_other;                                  // elements under other-letter keys inserted before this one
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (other_ids[mid] < i) lo = mid + 1; else hi = mid; }
+    const u64 element = wex[i >> 5] + (u64)__popc(bm[i >> 5] & ((1u << (i & 31)) - 1u)) + lo + 1;      // 1-based
     u32 gen = 0;
     for (int k = 1; k < gr.n; k++) if (gr.at[k] <= element) gen = (u32)k;
     const u64 o = oex[g];
@@ -763,6 +796,67 @@ __global__ __launch_bounds__(CT) void k_out_write(Src s, OutParams op, const u32
 
 }  // namespace
 
+// The table elements that come from reference windows with a letter outside A C G T N: CL:656-835 hashes every N-free window;
+// CheckIfComplementIsEarlier (CL:97-122) compares it with a "reverse complement" whose entries for such letters are NUL, and
+// the key is the window itself or that string cut at its first NUL.  No read-mer can equal such a key (they are never
+// printed), but they are elements: they count towards the table's growth and sit in its insertion order.  Returns the ids
+// (global position of the first window under each distinct key), ascending.  Host work on the few places concerned.
+static inline char oth_comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N'; } return 0; }
+static void other_letter_elements(const HostGenome &hg, u32 R, const FragFilter &ff, const std::vector<u64> &pk, const std::vector<u32> &bad,
+                                  std::vector<OtherLetter> &letters, std::vector<u32> &ids)
+{
+    std::sort(letters.begin(), letters.end(), [](const OtherLetter &a, const OtherLetter &b) { return a.g < b.g; });
+    std::unordered_set<std::string> seen;
+    std::string win(R, 'A'), key(R, 'A');
+    auto letter_at = [&](u64 g) -> char {
+        if ((bad[g >> 5] >> (31 - (g & 31))) & 1u) {
+            auto it = std::lower_bound(letters.begin(), letters.end(), (u32)g, [](const OtherLetter &a, u32 v) { return a.g < v; });
+            return (it != letters.end() && it->g == (u32)g) ? (char)it->ch : 'N';
+        }
+        return "ACGT"[(pk[g >> 5] >> (62 - 2 * (g & 31))) & 3u];
+    };
+    u64 next_start = 0;                                            // windows below this start have been looked at
+    for (size_t li = 0; li < letters.size(); li++) {
+        const u64 g = letters[li].g;
+        const u32 c = hg.contig_of(g);
+        const u64 cs = hg.gstart[c], ce = cs + hg.len[c];
+        if (hg.len[c] < R) continue;
+        u64 lo = g >= cs + (R - 1) ? g - (R - 1) : cs, hi = std::min<u64>(g, ce - R);       // window starts that cover the letter
+        if (lo < next_start) lo = next_start;
+        for (u64 st = lo; st <= hi && hi != (u64)-1; st++) {
+            bool has_n = false;
+            for (u32 k = 0; k < R; k++) { win[k] = letter_at(st + k); if (win[k] == 'N') { has_n = true; break; } }
+            if (has_n) continue;
+            if (ff.len) {                                          // fragmented mode: the window's end letters must spell a listed signal
+                u32 code = 0;
+                bool acgt = true;
+                const int pos[4] = {0, ff.len == 2 ? (int)R - 1 : 1, (int)R - 2, (int)R - 1};
+                for (u32 q = 0; q < ff.len; q++) {
+                    const char ch = win[pos[q]];
+                    const char *f = strchr("ACGT", ch);
+                    if (!f || !ch) { acgt = false; break; }
+                    code = code * 4 + (u32)(f - "ACGT");
+                }
+                if (!acgt || !((ff.mask[code >> 5] >> (code & 31)) & 1u)) continue;
+            }
+            size_t klen = R;
+            bool done = false;
+            for (u32 i = 0; i < R && !done; i++) {                 // CL:97-122
+                const char cc = oth_comp(win[R - 1 - i]);
+                if (win[i] < cc) { key = win; done = true; }
+                else if (win[i] > cc) {
+                    for (u32 k = 0; k < R; k++) key[k] = oth_comp(win[R - 1 - k]);
+                    for (u32 k = 0; k < R; k++) if (!key[k]) { klen = k; break; }
+                    done = true;
+                }
+            }
+            if (!done) key = win;
+            if (seen.insert(key.substr(0, klen)).second) ids.push_back((u32)st);
+        }
+        if (hi != (u64)-1 && hi + 1 > next_start) next_start = hi + 1;
+    }
+}
+
 struct cora_hip_collapse {
     cora_hip_collapse_params prm;
     u32 R = 0;
@@ -927,14 +1021,38 @@ int run_impl(cora_hip_collapse *c)
     st.distinct = n_groups;
     // The reference's table re-buckets itself with its first_rehash_at-th element, and again later (Growth): from then on the
     // order needs every element's number in the insertion order.  Windows with letters other than A C G T N are elements of
-    // that table too (under cut keys, never printed): their exact number and places are not derived here, so a run in which
-    // they could decide on which side of a growth step an element falls is refused.
+    // that table too (under keys of their own, never printed): which, and where in the insertion order, is worked out on the
+    // host when the table may grow (other_letter_elements).
     const u64 garbage_bound = other_letters * R;
-    const bool grown = n_groups + garbage_bound + 1 >= c->first_rehash_at;
-    if (grown && garbage_bound)
-        return fail(77, "%llu distinct read-mers + up to %llu reference windows with letters other than A C G T N: the reference's hash map "
-                        "re-buckets itself at %llu elements, and where those windows fall in its insertion order is not reproduced",
-                    (unsigned long long)n_groups, (unsigned long long)garbage_bound, (unsigned long long)c->first_rehash_at);
+    std::vector<u32> other_ids;                                    // ids of the elements under other-letter keys, ascending
+    DBuf<u32> d_other_ids;
+    if (n_groups + garbage_bound + 1 >= c->first_rehash_at && other_letters) {
+        if (other_letters > 100000)
+            return fail(77, "%llu reference letters other than A C G T N and a hash map that grows (%llu read-mers): their windows' places in the "
+                            "reference's insertion order are derived on the host, for up to 100000 such letters", (unsigned long long)other_letters,
+                        (unsigned long long)n_groups);
+        DBuf<OtherLetter> d_ol;
+        DBuf<u64> d_n;
+        RCQ(d_ol.alloc(other_letters + 1)); RCQ(d_n.alloc(1));
+        HIPQ(hipMemsetAsync(d_n.p, 0, 8, s));
+        hipLaunchKernelGGL(k_other_list, dim3(grid_of(dp.n_words, CT)), dim3(CT), 0, s, dp, rj->raw.p, rj->bad.p, d_ol.p, (u32)other_letters,
+                           (unsigned long long *)d_n.p);
+        u64 n_ol = 0;
+        HIPQ(hipMemcpyAsync(&n_ol, d_n.p, 8, hipMemcpyDeviceToHost, s));
+        HIPQ(hipStreamSynchronize(s));
+        if (n_ol != other_letters) return fail(100, "other-letter list holds %llu entries, the pack kernel counted %llu", (unsigned long long)n_ol, (unsigned long long)other_letters);
+        std::vector<OtherLetter> letters(n_ol);
+        std::vector<u64> h_pk(dp.n_words + 4);
+        std::vector<u32> h_bad(dp.n_words + 4);
+        HIPQ(hipMemcpy(letters.data(), d_ol.p, n_ol * sizeof(OtherLetter), hipMemcpyDeviceToHost));
+        HIPQ(hipMemcpy(h_pk.data(), rj->pk.p, (dp.n_words + 4) * sizeof(u64), hipMemcpyDeviceToHost));
+        HIPQ(hipMemcpy(h_bad.data(), rj->bad.p, (dp.n_words + 4) * sizeof(u32), hipMemcpyDeviceToHost));
+        other_letter_elements(rj->hg, R, c->frag, h_pk, h_bad, letters, other_ids);
+        RCQ(d_other_ids.alloc(other_ids.size() + 1));
+        if (!other_ids.empty()) HIPQ(hipMemcpyAsync(d_other_ids.p, other_ids.data(), other_ids.size() * sizeof(u32), hipMemcpyHostToDevice, s));
+    } else RCQ(d_other_ids.alloc(1));
+    const u64 elements = n_groups + other_ids.size();              // of the reference's table
+    const bool grown = elements >= c->first_rehash_at;
     RCQ(gstart.alloc(n_groups + 1));
     hipLaunchKernelGGL(k_group_starts, dim3(grid_of(N, CT)), dim3(CT), 0, s, head.p, gex.p, N, gstart.p, n_groups);
     head.release(); gex.release();
@@ -970,7 +1088,7 @@ int run_impl(cora_hip_collapse *c)
         // ---- the table grew (see k_mark_first ...): element numbers, generations, then one stable sort per bucket count ----
         const Growth &gr = c->growth;
         int g_last = 0;
-        for (int k = 1; k < gr.n; k++) if (gr.at[k] <= n_groups) g_last = k;
+        for (int k = 1; k < gr.n; k++) if (gr.at[k] <= elements) g_last = k;
         st.table_growth_steps = (u32)g_last;
         const u64 id_words = (std::min<u64>((u64)G + N, 1ull << 32) + 31) / 32 + 1;    // ids: reference positions below G, then G + read-mer index
         DBuf<u32> bm, wcnt, gen_start;
@@ -981,7 +1099,7 @@ int run_impl(cora_hip_collapse *c)
         hipLaunchKernelGGL(k_mark_first, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, sid, gstart.p, n_groups, bm.p);
         hipLaunchKernelGGL(k_word_popc, dim3(grid_of(id_words, CT)), dim3(CT), 0, s, bm.p, id_words, wcnt.p);
         RCQ(scan_u32(s, wcnt.p, wex.p, id_words, tot.p));
-        if (M) hipLaunchKernelGGL(k_growth_keys, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, sid, gstart.p, gflag.p, oex.p, n_groups, bm.p, wex.p, gr, okey.p, oval.p);
+        if (M) hipLaunchKernelGGL(k_growth_keys, dim3(grid_of(n_groups, CT)), dim3(CT), 0, s, sid, gstart.p, gflag.p, oex.p, n_groups, bm.p, wex.p, d_other_ids.p, (u32)other_ids.size(), gr, okey.p, oval.p);
         gflag.release(); oex.release(); wcnt.release();
         if (M && radix_sort(s, oa, ot, M, 0, 40, c->sort_scratch, &timing)) return fail(100, "radix sort failed");
         // oa: printed groups, generation by generation, latest element first; where each generation starts
