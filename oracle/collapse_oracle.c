@@ -53,7 +53,7 @@ static int n_growth = 7;            /* (the last entry lies beyond the 2^32 elem
 
 typedef struct {
     uint64_t hash;          /* FNV-1a 64 of the canonical read-mer */
-    uint32_t key;           /* offset of the key in the pool */
+    uint64_t key;           /* offset of the key in the pool */
     uint16_t klen;          /* its length: R, or less for the cut key of a window with a byte outside A C G T N */
     uint32_t ref_code;      /* 0 = not in the reference */
     uint32_t ref_pos;
@@ -121,10 +121,9 @@ static node_t *lookup(const char *key, int klen, int *created)
     if (n_nodes + 1 >= 0xFFFFFFFFull) { fprintf(stderr, "more than 2^32 distinct read-mers\n"); exit(77); }
     if (n_nodes == cap_nodes) { cap_nodes = cap_nodes ? cap_nodes * 2 : 1024; nodes = (node_t *)realloc(nodes, cap_nodes * sizeof(node_t)); }
     if (pool_len + R > pool_cap) { pool_cap = pool_cap ? pool_cap * 2 : (1u << 20); pool = (char *)realloc(pool, pool_cap); }
-    if (pool_len + R > 0xFFFFFFFFull) { fprintf(stderr, "key pool above 4 GiB\n"); exit(77); }
     node_t *nd = &nodes[n_nodes];
     memset(nd, 0, sizeof *nd);
-    nd->hash = h; nd->key = (uint32_t)pool_len; nd->klen = (uint16_t)klen;
+    nd->hash = h; nd->key = (uint64_t)pool_len; nd->klen = (uint16_t)klen;
     memcpy(pool + pool_len, key, (size_t)klen); pool_len += (size_t)klen;
     slots[p] = (uint32_t)n_nodes + 1;
     n_nodes++;
