@@ -10,7 +10,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     a = acc.setdefault(name, {})
     a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     a["_n"] = a.get("_n", 0) + (1 if r["Counter_Name"] == "SQ_WAVE_CYCLES" else 0)
-for name, a in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:14]:
+for name, a in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:40]:
     print(name[:60], "launches", a.pop("_n"))
     for k, v in sorted(a.items()):
         print("    %-24s %.4g" % (k, v))
