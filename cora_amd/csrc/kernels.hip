@@ -1085,8 +1085,10 @@ template <bool WRITE, bool SKB, bool SKC>
 __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__restrict__ codes, u64 n, u32 *__restrict__ cnt_slots /* [blocks * 256] */,
                                                     u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
                                                     PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c,
-                                                    u64 *__restrict__ staged /* [blocks * VT_QUOTA] */, u8 *__restrict__ blk_staged)
+                                                    u64 *__restrict__ staged /* [blocks * VT_QUOTA] */, u8 *__restrict__ blk_staged,
+                                                    const u8 *__restrict__ blk_mode /* 1: k_candidates_pairs has done this tile (null: none) */)
 {
+    if (blk_mode && blk_mode[blockIdx.x]) return;
     __shared__ u64 s_key[VT_TILE + VT_HALO];
     __shared__ u64 s_b[SKB ? VT_TILE + VT_HALO : 1];
     __shared__ u32 s_c[SKC ? VT_TILE + VT_HALO : 1];
@@ -1219,6 +1221,216 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
             blk_slots[blockIdx.x] = total;
             blk_staged[blockIdx.x] = keep_all ? 1 : 0;
             blk_cand[blockIdx.x] = c4[0] + c4[1] + c4[2] + c4[3];
+        }
+    }
+}
+
+// Inclusive scans over the 64 lanes of a wave in six DPP steps (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15
+// and 31 carry the row totals on): VALU moves, where __shfl_up goes through the LDS crossbar (ds_bpermute) every step.
+// 0 is the identity of both operations used here, and the value a lane keeps when its source lies outside its row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_or_zero(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ u32 wave_scan_max(u32 v)
+{
+    u32 t;
+    t = dpp_or_zero<0x111, 0xF>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x112, 0xF>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x114, 0xF>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x118, 0xF>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x142, 0xA>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x143, 0xC>(v); v = v > t ? v : t;
+    return v;
+}
+__device__ __forceinline__ u32 wave_scan_add(u32 v)
+{
+    v += dpp_or_zero<0x111, 0xF>(v);
+    v += dpp_or_zero<0x112, 0xF>(v);
+    v += dpp_or_zero<0x114, 0xF>(v);
+    v += dpp_or_zero<0x118, 0xF>(v);
+    v += dpp_or_zero<0x142, 0xA>(v);
+    v += dpp_or_zero<0x143, 0xC>(v);
+    return v;
+}
+
+// k_candidates, balanced.  The walk above gives every record to one lane, and a wave goes on until its longest walk has
+// ended: with 1.4 partners per record on average and runs of 20 in young repeat families most lanes idle most of the time
+// (8 100 VALU wave instructions per tile, a third of the wave cycles issuing).  Here the PAIRS of a wave's 512 records are
+// numbered and dealt out 64 at a time:
+//   1. run rank r of every record (how many earlier records of its run are in LDS) from a segmented scan of the head flags;
+//   2. pair q of the wave (q < W = sum of r) belongs to the record whose prefix sum P is the last one <= q: every record
+//      with r > 0 drops a marker (its index, P) at place P of a per-wave LDS strip, 512 places at a time, and an inclusive
+//      max-scan over the strip tells every lane whose pair it holds; the partner is the record q - P + 1 places before it.
+//   3. the sketch test, and a slot for what passes, ranked by (wave, q): the order of the slots does not depend on timing.
+// Tiles this cannot do -- a palindromic code (HTS:2769-2792: other slot kinds), a run that may go on before the LDS copy --
+// are left to k_candidates (blk_mode 0); k_candidates skips the others.
+constexpr int VP_STRIP = 128;
+template <bool WRITE, bool SKB, bool SKC>
+__global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64 *__restrict__ codes, u64 n, u32 *__restrict__ cnt_slots /* [blocks * 256] */,
+                                                          u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
+                                                          PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c,
+                                                          u64 *__restrict__ staged /* [blocks * VT_QUOTA] */, u8 *__restrict__ blk_staged,
+                                                          u8 *__restrict__ blk_mode)
+{
+    __shared__ u64 s_key[VT_TILE + VT_HALO];
+    __shared__ u64 s_b[SKB ? VT_TILE + VT_HALO : 1];
+    __shared__ u32 s_c[SKC ? VT_TILE + VT_HALO : 1];
+    __shared__ u32 s_mk[4][VP_STRIP];
+    __shared__ u32 s_val[WRITE ? 1 : VT_QUOTA];      // kept slots: (LDS slot of k-mer 1) << 16 | LDS slot of k-mer 2
+    __shared__ uint16_t s_own[WRITE ? 1 : VT_QUOTA]; // ... wave << 12 | rank among that wave's slots
+    __shared__ u32 s_seg[4], s_w[4];
+    __shared__ u32 s_n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 base = (u64)blockIdx.x * VT_TILE;
+    if (WRITE) {
+        if (!blk_mode[blockIdx.x] || blk_slots[blockIdx.x] == 0 || blk_staged[blockIdx.x]) return;    // not ours, nothing found, or all kept
+    }
+    if (!WRITE && tid == 0) s_n = 0;
+    const u64 lo = base >= (u64)VT_HALO ? base - VT_HALO : 0;       // first record held in LDS, at slot `first`
+    const int first = (int)(VT_HALO - (base - lo));
+    const u64 hi = base + VT_TILE < n ? base + VT_TILE : n;
+    {
+        constexpr int LD = (VT_TILE + VT_HALO) / 256;
+        u64 rk[LD], rb[SKB ? LD : 1];
+        u32 rc[SKC ? LD : 1];
+#pragma unroll
+        for (int q = 0; q < LD; q++) {
+            const u64 g = lo + (u64)(q * 256 + tid);
+            const bool in = g < hi;
+            rk[q] = in ? __builtin_nontemporal_load(codes + g) : 0ull;
+            if (SKB) rb[q] = in ? __builtin_nontemporal_load(sk_b + g) : 0ull;
+            if (SKC) rc[q] = in ? __builtin_nontemporal_load(sk_c + g) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < LD; q++) {
+            const int slot = first + q * 256 + tid;
+            if (slot < VT_TILE + VT_HALO) {
+                s_key[slot] = rk[q];
+                if (SKB) s_b[slot] = rb[q];
+                if (SKC) s_c[slot] = rc[q];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 1. run ranks: lane l of wave w owns records 512 w + 8 l .. + 7 of the tile ----
+    const int seg0 = VT_HALO + 512 * wv;                            // LDS slot of the wave's first record
+    const int slot0 = seg0 + 8 * lane;
+    const int n_tile = (int)(hi - base);                            // records of this tile (>= 1)
+    u32 code[9];
+    bool irregular = false;
+#pragma unroll
+    for (int j = 0; j < 9; j++) code[j] = (slot0 - 1 + j) >= first ? (u32)(s_key[slot0 - 1 + j] >> 32) : 0u;
+    bool head[8];
+    int last_head = -1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int sl = slot0 + j;
+        const bool valid = (sl - VT_HALO) < n_tile;
+        head[j] = !valid || sl == first || code[j + 1] != code[j];
+        if (head[j]) last_head = j;
+        if (valid && rc_code(code[j + 1]) == code[j + 1]) irregular = true;         // palindromic code: the walk's business
+    }
+    // Where each record's run starts (slot + 1): the latest head at or before it.  Across lanes that is a max-scan of every
+    // lane's last head; the wave's first record, when it continues a run, finds its start by walking back.
+    u32 carry_start_p1 = 0;
+    if (lane == 0 && !head[0]) {
+        int k = seg0 - 1;                                           // (equal to code[1], by !head[0])
+        while (k - 1 >= first && (u32)(s_key[k - 1] >> 32) == code[1]) k--;
+        carry_start_p1 = (u32)(k + 1);
+    }
+    const u32 incl = wave_scan_max(last_head >= 0 ? (u32)(slot0 + last_head + 1) : carry_start_p1);
+    u32 cur = __shfl_up(incl, 1, 64);                               // run start + 1 of the previous lane's last record
+    if (lane == 0) cur = carry_start_p1;
+    u32 r[8];
+    u32 lane_sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int sl = slot0 + j;
+        if (head[j]) cur = (u32)(sl + 1);
+        const u32 rank = (u32)(sl + 1) - cur;                       // earlier records of its run that are in LDS
+        r[j] = rank;
+        lane_sum += rank;
+        if (rank && cur == (u32)(first + 1) && lo > 0) irregular = true;     // the run may go on before the LDS copy
+    }
+    irregular = __syncthreads_or(irregular);
+    if (irregular) {
+        if (!WRITE && tid == 0) blk_mode[blockIdx.x] = 0;
+        return;
+    }
+    // ---- 2. pairs of the wave, 64 at a time ----
+    const u32 P = wave_scan_add(lane_sum);                          // inclusive scan of the lane sums
+    const u32 W = (u32)__builtin_amdgcn_readlane((int)P, 63);
+    u32 pr[8];
+    {
+        u32 x = P - lane_sum;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { pr[j] = x; x += r[j]; }
+    }
+    u32 seg_pre = 0;                                                // WRITE: slots of the waves before this one
+    if (WRITE) for (int w = 0; w < wv; w++) seg_pre += cnt_slots[(u64)blockIdx.x * 256 + w];
+    const u64 at0 = WRITE ? blk_off[blockIdx.x] + seg_pre : 0;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    u32 wslots = 0, carry_o = 0, carry_P = 0;
+    bool spill = false;
+    u32 *mk = s_mk[wv];
+    for (u32 c0 = 0; c0 < W; c0 += VP_STRIP) {
+#pragma unroll
+        for (int x = 0; x < VP_STRIP / 64; x++) mk[x * 64 + lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (r[j] && pr[j] >= c0 && pr[j] < c0 + VP_STRIP) mk[pr[j] - c0] = ((u32)(8 * lane + j + 1) << 16) | (pr[j] - c0);
+        __builtin_amdgcn_wave_barrier();
+        for (u32 t = 0; t < VP_STRIP && c0 + t < W; t += 64) {
+            const u32 q = c0 + t + lane;
+            const u32 v = wave_scan_max(mk[t + lane]);
+            const u32 o_rec = v ? (v >> 16) - 1u : carry_o;
+            const u32 o_P = v ? c0 + (v & 0xFFFFu) : carry_P;
+            carry_o = (u32)__builtin_amdgcn_readlane((int)o_rec, 63); carry_P = (u32)__builtin_amdgcn_readlane((int)o_P, 63);
+            bool pass = false;
+            int li = 0, lj = 0;
+            if (q < W) {
+                li = seg0 + (int)o_rec;
+                lj = li - (int)(q - o_P + 1u);
+                int mm = 0;
+                if (SKB) { const u64 x = s_b[li] ^ s_b[lj]; mm += __popcll((x | (x >> 1)) & M55); }
+                if (SKC) { const u32 y = s_c[li] ^ s_c[lj]; mm += __popc((y | (y >> 1)) & 0x55555555u); }
+                pass = mm <= p.d;
+            }
+            const u64 bal = __ballot(pass);
+            if (pass) {
+                const u32 rank = wslots + (u32)__popcll(bal & lt_mask);
+                if (WRITE) {
+                    PairRec rec;
+                    rec.p1 = (u32)s_key[li]; rec.p2 = (u32)s_key[lj]; rec.meta = SLOT_PLAIN;
+                    slots[at0 + rank] = rec;
+                } else {
+                    const u32 e = rank < 4096u ? atomicAdd(&s_n, 1u) : (u32)VT_QUOTA;
+                    if (e < (u32)VT_QUOTA) { s_val[WRITE ? 0 : e] = ((u32)li << 16) | (u32)lj; s_own[WRITE ? 0 : e] = (uint16_t)((wv << 12) | rank); }
+                    else spill = true;
+                }
+            }
+            wslots += (u32)__popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!WRITE) {
+        if (lane == 0) { s_seg[wv] = wslots; s_w[wv] = W; }
+        const bool keep = !__syncthreads_or(spill);                  // (the barrier also publishes s_seg, s_w, s_val, s_own)
+        const u32 total = s_seg[0] + s_seg[1] + s_seg[2] + s_seg[3];
+        const bool keep_all = keep && total <= (u32)VT_QUOTA;
+        if (keep_all) {
+            if ((u32)tid < total) {
+                const u32 e = s_val[WRITE ? 0 : tid], o = s_own[WRITE ? 0 : tid];
+                u32 pre = 0;
+                for (u32 w = 0; w < (o >> 12); w++) pre += s_seg[w];
+                staged[(u64)blockIdx.x * VT_QUOTA + pre + (o & 4095u)] = ((u64)(u32)s_key[e >> 16] << 32) | (u32)s_key[e & 0xFFFFu];
+            }
+        } else if (tid < 4) cnt_slots[(u64)blockIdx.x * 256 + tid] = s_seg[tid];      // the WRITE pass does this tile again
+        if (tid == 0) {
+            blk_mode[blockIdx.x] = 1;
+            blk_slots[blockIdx.x] = total;
+            blk_staged[blockIdx.x] = keep_all ? 1 : 0;
+            blk_cand[blockIdx.x] = (u64)s_w[0] + s_w[1] + s_w[2] + s_w[3];
         }
     }
 }
@@ -1948,27 +2160,35 @@ void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, con
 u64 verify_blocks(u64 n) { return (n + VT_TILE - 1) / VT_TILE; }
 template <bool WRITE>
 static void launch_candidates(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
-                              const u64 *blk_off, PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged)
+                              const u64 *blk_off, PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode)
 {
     if (!n) return;
     const dim3 g((unsigned)verify_blocks(n)), b(256);
-    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates<WRITE, true, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
-    else if (sk_b) hipLaunchKernelGGL((k_candidates<WRITE, true, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
-    else if (sk_c) hipLaunchKernelGGL((k_candidates<WRITE, false, true>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
-    else hipLaunchKernelGGL((k_candidates<WRITE, false, false>), g, b, 0, s, p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged);
+#define CAND_ARGS p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode
+    if (blk_mode) {                       // the balanced kernel takes the tiles it can do (and says which), the walk the others
+        if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates_pairs<WRITE, true, true>), g, b, 0, s, CAND_ARGS);
+        else if (sk_b) hipLaunchKernelGGL((k_candidates_pairs<WRITE, true, false>), g, b, 0, s, CAND_ARGS);
+        else if (sk_c) hipLaunchKernelGGL((k_candidates_pairs<WRITE, false, true>), g, b, 0, s, CAND_ARGS);
+        else hipLaunchKernelGGL((k_candidates_pairs<WRITE, false, false>), g, b, 0, s, CAND_ARGS);
+    }
+    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates<WRITE, true, true>), g, b, 0, s, CAND_ARGS);
+    else if (sk_b) hipLaunchKernelGGL((k_candidates<WRITE, true, false>), g, b, 0, s, CAND_ARGS);
+    else if (sk_c) hipLaunchKernelGGL((k_candidates<WRITE, false, true>), g, b, 0, s, CAND_ARGS);
+    else hipLaunchKernelGGL((k_candidates<WRITE, false, false>), g, b, 0, s, CAND_ARGS);
+#undef CAND_ARGS
 }
 u64 verify_staging_elems(u64 n) { return verify_blocks(n) * VT_QUOTA; }
 void launch_candidates_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
-                             const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged)
+                             const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode)
 {
-    launch_candidates<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged);
+    launch_candidates<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged, blk_mode);
 }
 void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, const u64 *blk_off,
-                             PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged)
+                             PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode)
 {
     if (!n) return;
     hipLaunchKernelGGL(k_staged_slots, dim3((unsigned)verify_blocks(n)), dim3(VT_QUOTA), 0, s, staged, blk_slots, blk_staged, blk_off, slots);
-    launch_candidates<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged);
+    launch_candidates<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode);
 }
 void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid)
 {

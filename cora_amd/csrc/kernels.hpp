@@ -108,10 +108,11 @@ u64 verify_blocks(u64 n);
 // staged[verify_staging_elems(n)], blk_staged[verify_blocks(n)]: the slots of the tiles the counting pass could keep whole
 u64 verify_staging_elems(u64 n);
 void launch_candidates_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
-                             const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged);
+                             const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged,
+                             u8 *blk_mode /* [blocks] which kernel did the tile; null: the walk (k_candidates) does them all */);
 void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots,
                              const u64 *blk_off /* scan of blk_slots */, PairRec *slots, const u64 *sk_b, const u32 *sk_c,
-                             u64 *staged, u8 *blk_staged);
+                             u64 *staged, u8 *blk_staged, u8 *blk_mode);
 void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid /* [ceil(n_slots / 256)] */);
 void launch_slot_compact(hipStream_t s, const PairRec *slots, u64 n_slots, const u64 *blk_off, PairRec *pairs);
 void launch_sum_u64(hipStream_t s, const u64 *in, u64 n, u64 *out /* device, accumulated into */);

@@ -271,7 +271,10 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         RCQ(cnt_slots.alloc(ab * 256)); RCQ(blk_slots.alloc(ab)); RCQ(blk_cand.alloc(ab));
         RCQ(slot_off.alloc(ab)); RCQ(scr_a.alloc(scan_scratch_elems(ab)));
         RCQ(staged.alloc(verify_staging_elems(n))); RCQ(blk_staged.alloc(ab));
-        launch_candidates_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p);
+        DBuf<u8> blk_mode;
+        static const bool pairs_kernel = !(getenv("CORA_PAIRS") && atoi(getenv("CORA_PAIRS")) == 0);      // (0: the walk does every tile)
+        if (pairs_kernel) RCQ(blk_mode.alloc(ab));
+        launch_candidates_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p);
         if (exclusive_scan_u32_to_u64(s, blk_slots.p, slot_off.p, ab, scr_a.p, tots.p)) return fail(100, "scan launch failed");
         HIPQ(hipMemsetAsync(tots.p + 1, 0, sizeof(u64), s));
         launch_sum_u64(s, blk_cand.p, ab, tots.p + 1);
@@ -282,7 +285,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         if (sk_b || sk_c) job->stats.seed_sketch = 1;
         if (totals[0] == 0) { HIPQ(hipGetLastError()); return 0; }
         RCQ(slots.alloc(totals[0]));
-        launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c, staged.p, blk_staged.p);
+        launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p);
     }
     const u64 n_slots = totals[0], jb = (n_slots + 255) / 256;
     DBuf<u32> blk_valid;
