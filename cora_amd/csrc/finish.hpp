@@ -57,6 +57,7 @@ struct InexactDeviceResult {           // directed items sorted by (source, targ
 struct ByteBuf {
     uint8_t *p = nullptr;
     size_t n = 0, cap = 0;
+    size_t mapped = 0;                   // > 0: p is an anonymous mapping of that many bytes (large buffers: huge pages asked for)
     bool reserve_uninit(size_t c);       // false: the host is out of memory (the buffer is then empty, p == nullptr)
     const uint8_t *data() const { return p; }
     size_t size() const { return n; }
