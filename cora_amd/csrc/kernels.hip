@@ -645,17 +645,12 @@ __global__ __launch_bounds__(256) void k_rep_mask_words(const u32 *__restrict__ 
     if (w < n_words) rep[w] = valid[w] & ~nonrep[w];
 }
 
-// rep[w] = valid windows of positions 32w..32w+31 (bit 31-i = position 32w+i) minus nonrep[w]; rep may alias nonrep
+// rep[w] = valid windows of positions 32w..32w+31 (bit 31-i = position 32w+i) minus nonrep[w]; rep may alias nonrep.
+// One thread per word (window_bits); sharded runs, where no rank's k_kmer_count has covered every position.
 __global__ __launch_bounds__(256) void k_rep_mask(DevParams p, const u32 *__restrict__ bad, const u32 *nonrep, u32 *rep)
 {
-    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = (g < p.G) && window_ok(p, bad, g);
-    const u64 bal = __ballot(ok);
-    const int lane = threadIdx.x & 63;
-    if (lane == 0 || lane == 32) {
-        const u64 w = g >> 5;
-        if (w < p.n_words) rep[w] = __brev((u32)(bal >> lane)) & ~nonrep[w];
-    }
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w < p.n_words) rep[w] = window_bits(p, bad, w) & ~nonrep[w];
 }
 
 // Lists the classes with >= 2 entries as rep<<32 | class index, at offsets from the scan of blk_nons.
@@ -2105,7 +2100,7 @@ void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u
 }
 void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep)
 {
-    hipLaunchKernelGGL(k_rep_mask, grid_for(p.G), dim3(256), 0, s, p, bad, nonrep, rep);
+    hipLaunchKernelGGL(k_rep_mask, grid_for(p.n_words), dim3(256), 0, s, p, bad, nonrep, rep);
 }
 void launch_mask_count(hipStream_t s, const u64 *mask, u64 n_words, u32 *blk_count)
 {

@@ -38,9 +38,20 @@ __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32 *lds_waves /*
     return base + x - v;
 }
 
+// The digit of a record: 8 key bits, or -- for the one-pass partition of records by the rank that owns them (multi-GPU
+// flow, shard.hip) -- the owner of the key's top 32 bits, taken as they are (dmode 1: hash ranges) or multiplied by the
+// golden ratio first (dmode 2: seed codes), scaled to `world` ranks.
+__device__ __forceinline__ u32 rs_digit(u64 word, int shift, u32 mask, u32 dmode, u32 world)
+{
+    if (dmode == 0) return (u32)(word >> shift) & mask;
+    u32 top = (u32)(word >> 32);
+    if (dmode == 2) top *= 0x9E3779B1u;
+    return (u32)(((u64)top * world) >> 32);
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u64 n, int shift, u32 mask,
-                                                    u32 *__restrict__ tile_hist)
+                                                    u32 *__restrict__ tile_hist, u32 dmode, u32 world)
 {
     constexpr int RS_THREADS = THREADS, RS_TILE = THREADS * RS_IPT;
     __shared__ u32 h[256];
@@ -55,14 +66,14 @@ __global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u6
         for (int k = 0; k < RS_IPT / 2; k++) { v[k].x = __builtin_nontemporal_load(&w2[k * RS_THREADS + tid].x); v[k].y = __builtin_nontemporal_load(&w2[k * RS_THREADS + tid].y); }
 #pragma unroll
         for (int k = 0; k < RS_IPT / 2; k++) {
-            atomicAdd(&h[(u32)(v[k].x >> shift) & mask], 1u);
-            atomicAdd(&h[(u32)(v[k].y >> shift) & mask], 1u);
+            atomicAdd(&h[rs_digit(v[k].x, shift, mask, dmode, world)], 1u);
+            atomicAdd(&h[rs_digit(v[k].y, shift, mask, dmode, world)], 1u);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < RS_IPT; k++) {
             u64 idx = base + (u64)k * RS_THREADS + tid;
-            if (idx < n) atomicAdd(&h[(u32)(w[idx] >> shift) & mask], 1u);
+            if (idx < n) atomicAdd(&h[rs_digit(w[idx], shift, mask, dmode, world)], 1u);
         }
     }
     __syncthreads();
@@ -166,7 +177,7 @@ template <bool HAS_B, bool HAS_C, bool DIG_B, int THREADS>
 __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_in, const u64 *__restrict__ b_in,
                                                           const u32 *__restrict__ c_in, u64 *__restrict__ a_out,
                                                           u64 *__restrict__ b_out, u32 *__restrict__ c_out, u64 n,
-                                                          int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg)
+                                                          int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg, u32 dmode, u32 world)
 {
     constexpr int RS_THREADS = THREADS, RS_TILE = THREADS * RS_IPT, RS_WAVES = THREADS / 64;
     __shared__ u64 stage[RS_TILE];          // 8 B per record of the tile
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
         const bool valid = (l0 + r * 64) < count;
-        const u32 d = (u32)(kw[r] >> shift) & mask;
+        const u32 d = rs_digit(kw[r], shift, mask, dmode, world);
         u64 peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
         if ((l0 + r * 64) < count) {
-            const u32 d = (u32)(kw[r] >> shift) & mask;
+            const u32 d = rs_digit(kw[r], shift, mask, dmode, world);
             lpos[r] += wcnt[wv][d];
             stage[lpos[r]] = kw[r];
         }
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
         const u32 i = k * RS_THREADS + tid;
         if (i < count) {
             const u64 v = stage[i];
-            dst[k] = delta[(u32)(v >> shift) & mask] + i;
+            dst[k] = delta[rs_digit(v, shift, mask, dmode, world)] + i;
             dig_out[dst[k]] = v;
         }
     }
@@ -362,15 +373,15 @@ void SortScratch::release()
 
 template <bool HAS_B, bool HAS_C>
 static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
-                           int shift, u32 mask, const u32 *tile_off, u32 xg)
+                           int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0)
 {
     constexpr int T = (HAS_C || HAS_B) ? 512 : 256;
     if (HAS_B && dig_b)
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg);
+                           out.c, n, shift, mask, tile_off, xg, dmode, world);
     else
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg);
+                           out.c, n, shift, mask, tile_off, xg, dmode, world);
 }
 
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi, SortScratch &scratch,
@@ -403,8 +414,8 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const u64 *word = dig_b ? keys.b : keys.a;
         u32 *th = scratch.tile_hist;
         if (pass == 0 && first_hist) th = first_hist;                    // the producer already counted this digit (tiles of radix_sort_tile_records())
-        else if (has_c || has_b) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th);
-        else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th);
+        else if (has_c || has_b) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th, 0u, 0u);
+        else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th, 0u, 0u);
         hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums);
         u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
         hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);
@@ -430,6 +441,55 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
             timing->scatter_bytes += 2 * rec_bytes * n;
         }
     }
+    RS_CHECK(hipGetLastError());
+    return 0;
+}
+
+// One stable pass that groups the records by the rank that owns them (rs_digit, dmode 1 or 2): the multi-GPU flow's
+// partition before an exchange.  Every array of the record moves in this one pass; the digit comes from keys.a.
+// counts[r] = records of rank r.  The result is in `keys` (the arrays are swapped, as in radix_sort).
+int radix_partition(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int dmode, u32 world, SortScratch &scratch, SortTiming *timing,
+                    uint64_t *counts)
+{
+    for (u32 r = 0; r < world; r++) counts[r] = 0;
+    if (n == 0) return 0;
+    if (n >= (1ull << 32) || world < 1 || world > 256 || (dmode != 1 && dmode != 2)) return (int)hipErrorInvalidValue;
+    const bool timed = timing && timing->enabled;
+    int rc = scratch.reserve(n);
+    if (rc) return rc;
+    if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
+    const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
+    const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
+    const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
+    const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
+    u32 *th = scratch.tile_hist;
+    if (has_c || has_b) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, keys.a, n, 0, 255u, th, (u32)dmode, world);
+    else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, keys.a, n, 0, 255u, th, (u32)dmode, world);
+    hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums);
+    u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
+    hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);
+    hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, th, tiles, chunk_off);
+    u32 starts[256];                                                 // row of tile 0: where each rank's records begin
+    RS_CHECK(hipMemcpyAsync(starts, th, world * sizeof(u32), hipMemcpyDeviceToHost, s));
+    if (timed) RS_CHECK(hipEventRecord(scratch.ev[0], s));
+    if (has_b) {
+        if (has_c) launch_scatter<true, true>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
+        else launch_scatter<true, false>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
+    } else {
+        if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
+        else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
+    }
+    if (timed) RS_CHECK(hipEventRecord(scratch.ev[1], s));
+    RS_CHECK(hipStreamSynchronize(s));
+    if (timed) {
+        float ms = 0.f;
+        RS_CHECK(hipEventElapsedTime(&ms, scratch.ev[0], scratch.ev[1]));
+        timing->scatter_ms += ms;
+        timing->scatter_launches += 1;
+        timing->scatter_bytes += 2 * (8 + (has_b ? 8 : 0) + (has_c ? 4 : 0)) * n;
+    }
+    for (u32 r = 0; r < world; r++) counts[r] = (r + 1 < world ? starts[r + 1] : (u64)n) - starts[r];
+    SortArrays t = keys; keys = tmp; tmp = t;
     RS_CHECK(hipGetLastError());
     return 0;
 }

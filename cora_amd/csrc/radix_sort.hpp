@@ -52,6 +52,10 @@ constexpr int RS_CHUNK_TILES = 64;                // tiles per column-scan workg
 // first_hist (optional): the [tiles of radix_sort_tile_records()][256] histogram of the first pass's digit, already
 // computed by whoever produced the records; it is consumed (turned into offsets in place).
 u32 radix_sort_tile_records(bool has_b, bool has_c);      // records per tile for that record shape
+// One stable pass grouping the records by owning rank (multi-GPU flow): owner = (top 32 bits of keys.a [dmode 2: times the golden
+// ratio, mod 2^32]) * world >> 32.  All arrays present in `keys` move together; counts[r] = records of rank r; result in `keys`.
+int radix_partition(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int dmode, u32 world, SortScratch &scratch, SortTiming *timing,
+                    uint64_t *counts);
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi,
                SortScratch &scratch, SortTiming *timing, u32 *first_hist = nullptr);
 

@@ -60,40 +60,27 @@ enum { SLOT_SEND_A = 0, SLOT_SEND_C, SLOT_RECV_A, SLOT_RECV_C, SLOT_REPMASK, SLO
 enum { ST_KMERS = 1, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH, ST_ITEM_CUT, ST_COLLECT };
 constexpr u32 N_STATS = 8;              // inexact_nodes, dirty, big, inexact_items, hom_pairs, candidate_pairs, 2 spare
 
-// stable partition of (a[, c]) by destination rank; counts[r] = records for rank r
+// stable partition of (a[, c][, b2]) by destination rank, all arrays in one scatter pass (radix_partition); counts[r] =
+// records for rank r.  mode 0: the top bits of a as they are (hash ranges), 1: hashed (seed codes).
 static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts, DBuf<u64> *b2 = nullptr)
 {
     hipStream_t s = job->stream;
     for (int r = 0; r < world; r++) counts[r] = 0;
     if (world == 1 || n == 0) { counts[0] = (world == 1) ? n : 0; return 0; }
-    DBuf<u64> dest, tdest, ta;
+    DBuf<u64> ta, tb;
     DBuf<u32> tc;
-    DBuf<unsigned long long> dcnt;
-    RCQ(dest.alloc(n)); RCQ(tdest.alloc(n)); RCQ(ta.alloc(n)); RCQ(dcnt.alloc(256));
+    RCQ(ta.alloc(n));
     if (c) RCQ(tc.alloc(n));
-    HIPQ(hipMemsetAsync(dcnt.p, 0, 256 * sizeof(unsigned long long), s));
-    launch_dest_keys(s, a.p, n, mode, (u32)world, dest.p);
-    launch_count_dest(s, dest.p, n, (u32)world, dcnt.p);
-    if (b2) {                                                 // the same stable pass over (dest, b2): the same permutation
-        DBuf<u64> dest2, tdest2, tb;
-        RCQ(dest2.alloc(n)); RCQ(tdest2.alloc(n)); RCQ(tb.alloc(n));
-        HIPQ(hipMemcpyAsync(dest2.p, dest.p, n * sizeof(u64), hipMemcpyDeviceToDevice, s));
-        SortArrays k2, t2;
-        k2.a = dest2.p; k2.b = b2->p; t2.a = tdest2.p; t2.b = tb.p;
-        if (radix_sort(s, k2, t2, n, 64, 72, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-        HIPQ(hipStreamSynchronize(s));
-        if (k2.b != b2->p) std::swap(b2->p, tb.p);
-    }
+    if (b2) RCQ(tb.alloc(n));
     SortArrays keys, tmp;
-    keys.a = dest.p; keys.b = a.p; keys.c = c ? c->p : nullptr;
-    tmp.a = tdest.p; tmp.b = ta.p; tmp.c = c ? tc.p : nullptr;
-    if (radix_sort(s, keys, tmp, n, 64, 72, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-    unsigned long long h[256];
-    HIPQ(hipMemcpyAsync(h, dcnt.p, sizeof h, hipMemcpyDeviceToHost, s));
-    HIPQ(hipStreamSynchronize(s));
+    keys.a = a.p; keys.b = b2 ? b2->p : nullptr; keys.c = c ? c->p : nullptr;
+    tmp.a = ta.p; tmp.b = b2 ? tb.p : nullptr; tmp.c = c ? tc.p : nullptr;
+    if (radix_partition(s, keys, tmp, n, mode == 0 ? 1 : 2, (u32)world, job->sort_scratch, &job->sort_timing, counts)) return fail(100, "partition failed");
     HIPQ(hipGetLastError());
-    if (keys.b != a.p) { std::swap(a.p, ta.p); if (c) std::swap(c->p, tc.p); }     // one pass: the result sits in the tmp arrays
-    for (int r = 0; r < world; r++) counts[r] = h[r];
+    // one pass: the result sits in what were the spare arrays
+    std::swap(a.p, ta.p);
+    if (c) std::swap(c->p, tc.p);
+    if (b2) std::swap(b2->p, tb.p);
     return 0;
 }
 
