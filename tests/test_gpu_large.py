@@ -57,8 +57,8 @@ def _build_and_check(contigs, K, d, p, t, tmp_path, repeat=True, L=False):
 
 
 def test_config2_grch38_sized_reference(tmp_path):
-    """3.09 Gbp in 25 contigs (bench.py's workload): the 48-bit hash regime of the exact sort (above 2^27 records), the sketches
-    switched on by the size itself (not by CORA_SKETCH), per-seed record generation."""
+    """3.09 Gbp in 25 contigs (bench.py's workload): the exact sort on 40 hash bits with 2e6 collision places to repair, the sketches
+    switched on by the size itself (not by CORA_SKETCH), per-seed record generation, the balanced candidate kernel."""
     assert "CORA_SKETCH" not in os.environ and "CORA_HASH_BITS" not in os.environ
     hip.init(0)
     st, out = _build_and_check(synth.workload_grch38_like(38, 1.0), 50, 2, 10, 8, tmp_path)
