@@ -2252,17 +2252,9 @@ __global__ __launch_bounds__(256) void k_gather_parts(const u64 *__restrict__ ke
     ce_s[k] = ce[idx]; eoff_s[k] = eoff[idx];
 }
 
-// destination rank of a record: mode 0 = range of the top 32 bits (uniform hashes), mode 1 = multiplicative
-// hash of the top 32 bits (canonical seed codes are skewed towards small values)
-__global__ __launch_bounds__(256) void k_dest_keys(const u64 *__restrict__ a, u64 n, int mode, u32 world, u64 *__restrict__ dest)
-{
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    u32 top = (u32)(a[i] >> 32);
-    if (mode == 1) top *= 0x9E3779B1u;
-    dest[i] = ((u64)top * world) >> 32;
-}
-
+// records per destination rank (the items' partition; k-mer and seed records are partitioned by radix_partition, whose
+// digit is the owner: range of the top 32 bits for the uniform hashes, a multiplicative hash of them for the canonical seed
+// codes, which are skewed towards small values)
 __global__ __launch_bounds__(256) void k_count_dest(const u64 *__restrict__ dest, u64 n, u32 world, unsigned long long *__restrict__ counts)
 {
     __shared__ u32 h[256];
@@ -2319,10 +2311,6 @@ void launch_rekey(hipStream_t s, const u64 *cls, u32 n, u64 *key)
 void launch_gather_parts(hipStream_t s, const u64 *key_sorted, u32 n, const u32 *ce, const u64 *eoff, u32 *ce_s, u64 *eoff_s)
 {
     if (n) hipLaunchKernelGGL(k_gather_parts, grid_for(n), dim3(256), 0, s, key_sorted, n, ce, eoff, ce_s, eoff_s);
-}
-void launch_dest_keys(hipStream_t s, const u64 *a, u64 n, int mode, u32 world, u64 *dest)
-{
-    if (n) hipLaunchKernelGGL(k_dest_keys, grid_for(n), dim3(256), 0, s, a, n, mode, world, dest);
 }
 void launch_count_dest(hipStream_t s, const u64 *dest, u64 n, u32 world, unsigned long long *counts)
 {

@@ -142,7 +142,6 @@ namespace cora {
 void launch_keys_from_gpos(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *gpos, u64 n, u64 *hi, u64 *lo);
 void launch_rekey(hipStream_t s, const u64 *cls, u32 n, u64 *key);
 void launch_gather_parts(hipStream_t s, const u64 *key_sorted, u32 n, const u32 *ce, const u64 *eoff, u32 *ce_s, u64 *eoff_s);
-void launch_dest_keys(hipStream_t s, const u64 *a, u64 n, int mode, u32 world, u64 *dest);
 void launch_window_counts(hipStream_t s, const u64 *item_key, u64 m, const u32 *bnd, u32 n_bnd, u32 win, u32 *wc);
 void launch_dest_by_cuts(hipStream_t s, const u64 *item_key, u64 m, const u32 *cuts, u32 n_cuts, u64 *dest);
 void launch_count_dest(hipStream_t s, const u64 *dest, u64 n, u32 world, unsigned long long *counts);
