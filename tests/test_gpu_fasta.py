@@ -185,3 +185,30 @@ def test_full_size_scan_equals_the_oracle(tmp_path):
         assert info["conforming"] == 1 and info["bases"] == 64_000_000
     finally:
         f.close()
+
+
+def test_image_above_half_a_gigabyte_goes_up_through_the_staged_upload(tmp_path):
+    """From 512 MB on the image is uploaded by six host threads through pinned buffers (fasta.hip: upload_pageable) instead of
+    one hipMemcpy from pageable memory: the scan must see the same bytes (.fai against the oracle, base count), also for a
+    size that is no multiple of the 8 MB chunks."""
+    import mmap
+    rs = np.random.RandomState(77)
+    contigs = [("c%d" % i, synth.random_seq(rs, n)) for i, n in enumerate((190_000_001, 170_000_000, 151_234_567, 60_000_003, 977))]
+    image = synth.fasta_image(contigs, 60)[0]
+    total = sum(len(s) for _, s in contigs)
+    del contigs
+    p = str(tmp_path / "half_g.fa")
+    open(p, "wb").write(bytes(image))
+    del image
+    want = subprocess.run([build_fai_oracle(), p], stdout=subprocess.PIPE, check=True).stdout
+    with open(p, "rb") as fh:
+        m = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        assert len(m) > 512 * 1024 * 1024 and len(m) % (8 << 20) != 0
+        f = hip.Fasta(m)
+        try:
+            assert f.fai_text() == want
+            info = f.info()
+            assert info["conforming"] == 1 and info["bases"] == total
+        finally:
+            f.close()
+            m.close()
