@@ -10,9 +10,10 @@ it (`--workload grch38_like`): 3.09 Gbp in 25 contigs with the GRCh38 primary-as
 45 % of the bases from repeat families (cora_amd/synth.py: workload_grch38_like says how the copy numbers are capped and
 why), K=50, d=2, cora's default split files (`-p 10 -t 8`: lines 10 and 8 of LPT_2.dat / LPT_4.dat).
 
-N > 1 is STRONG scaling on that same fixed reference: every rank holds the packed reference, scans 1/N of the positions
-and owns 1/N of the key space; records move by all-to-all over RCCL (cora_amd/dist.py) and rank 0 ends up with both
-tables.  Started without a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the script starts its N ranks itself,
+N > 1 is STRONG scaling on that same fixed reference: every rank holds the packed reference and owns 1/N of the key
+space.  On 2 to 4 GPUs (one xGMI link per GPU pair) every rank scans all positions and keeps the records it owns; above
+that it scans 1/N of the positions and the records move by all-to-all over RCCL (cora_amd/dist.py, shard.hip).  Rank 0 ends
+up with both tables.  Started without a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the script starts its N ranks itself,
 before anything touches a GPU; under `python -m torch.distributed.run` it is one of the ranks.
 
 Outside the timed region, on rank 0 at N=1: the last step's tables are written out, checked record by record against the
@@ -269,7 +270,9 @@ def main():
         achieved = (sc_bytes / 1e9) / (sc_ms / 1e3) if sc_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(tag, K, d) if world == 1 else (None, None)
         if sharded:
-            par_txt = "sharded (strong scaling): positions and key space of the one reference split over %d GPUs, all-to-all over %s" % (world, a.backend)
+            par_txt = ("sharded (strong scaling): key space of the one reference split over %d GPUs; %s; items, bitmaps and table parts over %s"
+                       % (world, "every rank scans all positions and keeps the records it owns (2 to 4 GPUs: one xGMI link per pair)" if sj.kept_own
+                          else "1/%d of the positions scanned per rank, records to their owner by all-to-all" % world, a.backend))
         elif world > 1:
             par_txt = "replicas: 1 independent reference per GPU"
         else:

@@ -27,6 +27,7 @@ int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const void *src_devi
 int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t n_elems, void **ptr);
 int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
 int cora_hip_shard_seed_sketch(cora_hip_job *job, int *on);
+int cora_hip_shard_filter(cora_hip_job *job, int set, int *on);
 int cora_hip_shard_set_first_singleton(cora_hip_job *job, uint64_t key);
 }
 
@@ -221,8 +222,12 @@ struct Rank {
 
         TRY(cora_hip_shard_begin(job, r, world));
         if (!sync()) return;
-        // exact: K-mer records to the owner of their hash range
-        if (!all_to_all(CORA_ST_KMERS, 0, send_ac, recv_ac, eb_rec, 2)) return;
+        // exact: K-mer records to the owner of their hash range -- by all-to-all, or (2 to 4 ranks: shard.hip) every rank scans all
+        // positions and keeps its own; the same choice on every rank (same world, same environment)
+        int filter = 0;
+        TRY(cora_hip_shard_filter(job, -1, &filter));
+        if (filter) TRY(cora_hip_shard_stage(job, CORA_ST_KMERS, 0, nullptr));
+        else if (!all_to_all(CORA_ST_KMERS, 0, send_ac, recv_ac, eb_rec, 2)) return;
         TRY(cora_hip_shard_stage(job, CORA_ST_EXACT, 0, nullptr));
         TRY(cora_hip_shard_get_first_singleton(job, &t.pub[r].value));
         if (!sync()) return;
@@ -242,7 +247,8 @@ struct Rank {
         static const uint32_t eb_code2[2] = {8, 8};
         const bool sketched = job->dp.nseeds >= 3 && (job->sketch_mode >= 0 ? job->sketch_mode != 0 : job->dp.G > (1ull << 28));
         for (int seed = 1; seed <= job->dp.nseeds; seed++) {
-            if (!(sketched ? all_to_all(CORA_ST_SEED, seed, send_ab, recv_ab, eb_code2, 2) : all_to_all(CORA_ST_SEED, seed, send_a, recv_a, eb_code, 1))) return;
+            if (filter) TRY(cora_hip_shard_stage(job, CORA_ST_SEED, seed, nullptr));
+            else if (!(sketched ? all_to_all(CORA_ST_SEED, seed, send_ab, recv_ab, eb_code2, 2) : all_to_all(CORA_ST_SEED, seed, send_a, recv_a, eb_code, 1))) return;
             TRY(cora_hip_shard_stage(job, CORA_ST_VERIFY, seed, nullptr));
         }
         // lists are finished by the owner of their source position; intervals are cut where a position holds no list

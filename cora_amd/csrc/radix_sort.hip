@@ -177,8 +177,11 @@ template <bool HAS_B, bool HAS_C, bool DIG_B, int THREADS>
 __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_in, const u64 *__restrict__ b_in,
                                                           const u32 *__restrict__ c_in, u64 *__restrict__ a_out,
                                                           u64 *__restrict__ b_out, u32 *__restrict__ c_out, u64 n,
-                                                          int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg, u32 dmode, u32 world)
+                                                          int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg, u32 dmode, u32 world,
+                                                          u32 keep)
 {
+    // keep != RS_KEEP_ALL: only the records of digit `keep` are written, packed from index 0 of the output arrays (the
+    // multi-GPU flow's "scan everything, keep what I own": radix_partition_move)
     constexpr int RS_THREADS = THREADS, RS_TILE = THREADS * RS_IPT, RS_WAVES = THREADS / 64;
     __shared__ u64 stage[RS_TILE];          // 8 B per record of the tile
     __shared__ u32 wcnt[RS_WAVES][256];            // per-wave digit counters, then per-wave digit bases
@@ -262,7 +265,8 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
             u32 run = start;
 #pragma unroll
             for (int w = 0; w < RS_WAVES; w++) { wcnt[w][dg] = run; run += c[w]; }
-            delta[tid] = tile_off[(size_t)tile * 256 + tid] - start;
+            // (row 0 of the scanned histogram = where each digit's records begin: the kept digit's output starts at 0)
+            delta[tid] = tile_off[(size_t)tile * 256 + tid] - start - (keep != RS_KEEP_ALL ? tile_off[keep] : 0u);
         }
     }
     __syncthreads();
@@ -290,10 +294,14 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
     for (int k = 0; k < RS_IPT; k++) {
         const u32 i = k * RS_THREADS + tid;
+        dst[k] = RS_KEEP_ALL;                 // (no record goes to index 2^32 - 1: n < 2^32)
         if (i < count) {
             const u64 v = stage[i];
-            dst[k] = delta[rs_digit(v, shift, mask, dmode, world)] + i;
-            dig_out[dst[k]] = v;
+            const u32 dg = rs_digit(v, shift, mask, dmode, world);
+            if (keep == RS_KEEP_ALL || dg == keep) {
+                dst[k] = delta[dg] + i;
+                dig_out[dst[k]] = v;
+            }
         }
     }
     if (HAS_B) {
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int k = 0; k < RS_IPT; k++) {
             const u32 i = k * RS_THREADS + tid;
-            if (i < count) oth_out[dst[k]] = stage[i];
+            if (i < count && dst[k] != RS_KEEP_ALL) oth_out[dst[k]] = stage[i];
         }
     }
     if (HAS_C) {
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int k = 0; k < RS_IPT; k++) {
             const u32 i = k * RS_THREADS + tid;
-            if (i < count) c_out[dst[k]] = stage32[i];
+            if (i < count && dst[k] != RS_KEEP_ALL) c_out[dst[k]] = stage32[i];
         }
     }
 }
@@ -373,15 +381,15 @@ void SortScratch::release()
 
 template <bool HAS_B, bool HAS_C>
 static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
-                           int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0)
+                           int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0, u32 keep = RS_KEEP_ALL)
 {
     constexpr int T = (HAS_C || HAS_B) ? 512 : 256;
     if (HAS_B && dig_b)
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg, dmode, world);
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, keep);
     else
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg, dmode, world);
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, keep);
 }
 
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi, SortScratch &scratch,
@@ -446,18 +454,18 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
 }
 
 // One stable pass that groups the records by the rank that owns them (rs_digit, dmode 1 or 2): the multi-GPU flow's
-// partition before an exchange.  Every array of the record moves in this one pass; the digit comes from keys.a.
-// counts[r] = records of rank r.  The result is in `keys` (the arrays are swapped, as in radix_sort).
-int radix_partition(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int dmode, u32 world, SortScratch &scratch, SortTiming *timing,
-                    uint64_t *counts)
+// partition.  Every array of the record moves in this one pass; the digit comes from keys.a.  Two calls, because the
+// caller sizes the output from the counts:
+//   radix_partition_count   histogram + offsets; counts[r] = records of rank r (synchronises the stream)
+//   radix_partition_move    the scatter, straight after the count on the same arrays.  keep < 0: all n records, grouped by
+//                           rank, into `out`; keep = r: only rank r's records, packed from index 0 (out holds counts[r]).
+int radix_partition_count(hipStream_t s, const SortArrays &keys, u64 n, int dmode, u32 world, SortScratch &scratch, uint64_t *counts)
 {
     for (u32 r = 0; r < world; r++) counts[r] = 0;
     if (n == 0) return 0;
     if (n >= (1ull << 32) || world < 1 || world > 256 || (dmode != 1 && dmode != 2)) return (int)hipErrorInvalidValue;
-    const bool timed = timing && timing->enabled;
     int rc = scratch.reserve(n);
     if (rc) return rc;
-    if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
     const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
     const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
     const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
@@ -471,13 +479,31 @@ int radix_partition(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int
     hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, th, tiles, chunk_off);
     u32 starts[256];                                                 // row of tile 0: where each rank's records begin
     RS_CHECK(hipMemcpyAsync(starts, th, world * sizeof(u32), hipMemcpyDeviceToHost, s));
+    RS_CHECK(hipStreamSynchronize(s));
+    for (u32 r = 0; r < world; r++) counts[r] = (r + 1 < world ? starts[r + 1] : (u64)n) - starts[r];
+    RS_CHECK(hipGetLastError());
+    return 0;
+}
+
+int radix_partition_move(hipStream_t s, const SortArrays &keys, const SortArrays &out, u64 n, int dmode, u32 world, int keep, u64 n_kept,
+                         SortScratch &scratch, SortTiming *timing)
+{
+    if (n == 0) return 0;
+    if (n >= (1ull << 32) || world < 1 || world > 256 || (dmode != 1 && dmode != 2) || keep >= (int)world) return (int)hipErrorInvalidValue;
+    const bool timed = timing && timing->enabled;
+    if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
+    const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
+    const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
+    const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
+    u32 *th = scratch.tile_hist;                                     // as radix_partition_count left it
+    const u32 kp = keep < 0 ? RS_KEEP_ALL : (u32)keep;
     if (timed) RS_CHECK(hipEventRecord(scratch.ev[0], s));
     if (has_b) {
-        if (has_c) launch_scatter<true, true>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
-        else launch_scatter<true, false>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
+        if (has_c) launch_scatter<true, true>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
+        else launch_scatter<true, false>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
     } else {
-        if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
-        else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
+        if (has_c) launch_scatter<false, true>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
+        else launch_scatter<false, false>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
     }
     if (timed) RS_CHECK(hipEventRecord(scratch.ev[1], s));
     RS_CHECK(hipStreamSynchronize(s));
@@ -486,10 +512,8 @@ int radix_partition(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int
         RS_CHECK(hipEventElapsedTime(&ms, scratch.ev[0], scratch.ev[1]));
         timing->scatter_ms += ms;
         timing->scatter_launches += 1;
-        timing->scatter_bytes += 2 * (8 + (has_b ? 8 : 0) + (has_c ? 4 : 0)) * n;
+        timing->scatter_bytes += (8 + (has_b ? 8 : 0) + (has_c ? 4 : 0)) * (n + (keep < 0 ? n : n_kept));     // read all, write what is kept
     }
-    for (u32 r = 0; r < world; r++) counts[r] = (r + 1 < world ? starts[r + 1] : (u64)n) - starts[r];
-    SortArrays t = keys; keys = tmp; tmp = t;
     RS_CHECK(hipGetLastError());
     return 0;
 }

@@ -18,12 +18,21 @@
 //
 // Equal keys (codes) meet on one rank; inside each received chunk they are in increasing position and chunks
 // arrive in rank = position order, so the stable sorts see them exactly as the single-GPU run does.
+//
+// Two ways to bring a rank its K-mer and seed records (`filter` below; the same tables either way):
+//   exchange   as above: 1/R of the positions scanned, the records partitioned by owner and moved by all-to-all.  28 B per k-mer
+//              and 16 B per representative and seed cross the links: fine over 7 links at once, link-bound on 2 or 4 GPUs,
+//              where a GPU pair has ONE xGMI link between them.
+//   filter     every rank holds the whole packed reference anyway: it scans ALL positions itself and keeps the records it
+//              owns (one scatter pass that writes only its own digit).  Nothing crosses a link for KMERS and SEED; the price is a
+//              scan that does not shrink with R.  Chosen for world <= 4 (CORA_SHARD_FILTER=0/1 overrides).
 #include "job_internal.hpp"
 
 using namespace cora;
 
 struct ShardState {
     int rank = 0, world = 1;
+    bool filter = false;                // K-mer and seed records: scan everything and keep the own ones, instead of the exchange
     u32 blk_lo = 0, blk_n = 0;
     u64 word_lo = 0, word_hi = 0;
     DBuf<u64> send_a, recv_a, send_b, recv_b;       // b: the seed records' sketches (large references), moved like a
@@ -60,27 +69,37 @@ enum { SLOT_SEND_A = 0, SLOT_SEND_C, SLOT_RECV_A, SLOT_RECV_C, SLOT_REPMASK, SLO
 enum { ST_KMERS = 1, ST_EXACT, ST_PARTS, ST_MERGE, ST_REPS, ST_SEED, ST_VERIFY, ST_ITEMS, ST_FINISH, ST_ITEM_CUT, ST_COLLECT };
 constexpr u32 N_STATS = 8;              // inexact_nodes, dirty, big, inexact_items, hom_pairs, candidate_pairs, 2 spare
 
-// stable partition of (a[, c][, b2]) by destination rank, all arrays in one scatter pass (radix_partition); counts[r] =
-// records for rank r.  mode 0: the top bits of a as they are (hash ranges), 1: hashed (seed codes).
-static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts, DBuf<u64> *b2 = nullptr)
+template <typename T>
+static void swap_buf(DBuf<T> &x, DBuf<T> &y)
+{
+    std::swap(x.p, y.p); std::swap(x.n, y.n); std::swap(x.pool, y.pool);
+}
+
+// stable partition of (a[, c][, b2]) by destination rank, all arrays in one scatter pass (radix_partition_*); counts[r] =
+// records for rank r.  mode 0: the top bits of a as they are (hash ranges), 1: hashed (seed codes).  keep >= 0: only that
+// rank's records survive (the arrays then hold counts[keep] records).
+static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts, DBuf<u64> *b2 = nullptr,
+                             int keep = -1)
 {
     hipStream_t s = job->stream;
     for (int r = 0; r < world; r++) counts[r] = 0;
     if (world == 1 || n == 0) { counts[0] = (world == 1) ? n : 0; return 0; }
+    const int dmode = mode == 0 ? 1 : 2;
+    SortArrays keys, out;
+    keys.a = a.p; keys.b = b2 ? b2->p : nullptr; keys.c = c ? c->p : nullptr;
+    if (radix_partition_count(s, keys, n, dmode, (u32)world, job->sort_scratch, counts)) return fail(100, "partition failed");
+    const u64 n_out = keep < 0 ? n : counts[keep];
     DBuf<u64> ta, tb;
     DBuf<u32> tc;
-    RCQ(ta.alloc(n));
-    if (c) RCQ(tc.alloc(n));
-    if (b2) RCQ(tb.alloc(n));
-    SortArrays keys, tmp;
-    keys.a = a.p; keys.b = b2 ? b2->p : nullptr; keys.c = c ? c->p : nullptr;
-    tmp.a = ta.p; tmp.b = b2 ? tb.p : nullptr; tmp.c = c ? tc.p : nullptr;
-    if (radix_partition(s, keys, tmp, n, mode == 0 ? 1 : 2, (u32)world, job->sort_scratch, &job->sort_timing, counts)) return fail(100, "partition failed");
+    RCQ(ta.alloc(n_out));
+    if (c) RCQ(tc.alloc(n_out));
+    if (b2) RCQ(tb.alloc(n_out));
+    out.a = ta.p; out.b = b2 ? tb.p : nullptr; out.c = c ? tc.p : nullptr;
+    if (radix_partition_move(s, keys, out, n, dmode, (u32)world, keep, n_out, job->sort_scratch, &job->sort_timing)) return fail(100, "partition failed");
     HIPQ(hipGetLastError());
-    // one pass: the result sits in what were the spare arrays
-    std::swap(a.p, ta.p);
-    if (c) std::swap(c->p, tc.p);
-    if (b2) std::swap(b2->p, tb.p);
+    swap_buf(a, ta);
+    if (c) swap_buf(*c, tc);
+    if (b2) swap_buf(*b2, tb);
     return 0;
 }
 
@@ -93,6 +112,9 @@ extern "C" int cora_hip_shard_begin(cora_hip_job *job, int rank, int world)
     ShardState *sh = new ShardState();
     job->shard = sh;
     sh->rank = rank; sh->world = world;
+    // one xGMI link per GPU pair: on 2 or 4 GPUs the all-to-all of the records costs more than scanning everything locally
+    sh->filter = world > 1 && world <= 4;
+    if (const char *e = getenv("CORA_SHARD_FILTER")) sh->filter = world > 1 && atoi(e) != 0;
     const DevParams &dp = job->dp;
     const u64 n_blocks = (dp.G + 255) / 256;                 // G is a multiple of 64; a block covers 8 bitmap words
     const u64 b0 = n_blocks * rank / world, b1 = n_blocks * (rank + 1) / world;
@@ -126,6 +148,14 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     if (!counts) counts = local_counts;
     switch (stage) {
     case ST_KMERS: {
+        if (sh.filter) {                // all positions; what the partition keeps is this rank's received set
+            RCQ(st_kmers(job, 0, (u32)((dp.G + 255) / 256), sh.send_a, sh.send_c, sh.n_send));
+            RCQ(partition_by_dest(job, sh.send_a, &sh.send_c, sh.n_send, 0, sh.world, counts, nullptr, sh.rank));
+            swap_buf(sh.recv_a, sh.send_a); swap_buf(sh.recv_c, sh.send_c);
+            sh.n_recv = counts[sh.rank]; sh.n_send = 0;
+            sh.send_a.release(); sh.send_c.release();
+            return 0;
+        }
         RCQ(st_kmers(job, sh.blk_lo, sh.blk_n, sh.send_a, sh.send_c, sh.n_send));
         RCQ(partition_by_dest(job, sh.send_a, &sh.send_c, sh.n_send, 0, sh.world, counts));
         return 0;
@@ -154,7 +184,8 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     }
     case ST_REPS: {
         if (!sh.repmask_g.p) return fail(19, "the global representative bitmap has not been imported");
-        RCQ(st_reps(job, sh.repmask_g.p, sh.word_lo, sh.word_hi, sh.reps, sh.n_reps));
+        if (sh.filter) RCQ(st_reps(job, sh.repmask_g.p, 0, dp.n_words, sh.reps, sh.n_reps));
+        else RCQ(st_reps(job, sh.repmask_g.p, sh.word_lo, sh.word_hi, sh.reps, sh.n_reps));
         return 0;
     }
     case ST_SEED: {
@@ -177,7 +208,14 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
             launch_seed_codes(s, dp, job->pk.p, sh.reps.p, sh.n_reps, arg, sh.send_a.p);
         }
         HIPQ(hipStreamSynchronize(s));
-        RCQ(partition_by_dest(job, sh.send_a, nullptr, sh.n_send, 1, sh.world, counts, sh.seed_sketch ? &sh.send_b : nullptr));
+        RCQ(partition_by_dest(job, sh.send_a, nullptr, sh.n_send, 1, sh.world, counts, sh.seed_sketch ? &sh.send_b : nullptr,
+                              sh.filter ? sh.rank : -1));
+        if (sh.filter) {
+            swap_buf(sh.recv_a, sh.send_a);
+            if (sh.seed_sketch) swap_buf(sh.recv_b, sh.send_b); else sh.recv_b.release();
+            sh.n_recv = counts[sh.rank]; sh.n_send = 0;
+            sh.send_a.release(); sh.send_b.release();
+        }
         return 0;
     }
     case ST_VERIFY: {
@@ -406,6 +444,18 @@ extern "C" int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t
     default: return fail(19, "slot %d cannot be reserved", slot);
     }
     HIPQ(hipStreamSynchronize(job->stream));
+    return 0;
+}
+
+// How this build brings a rank its K-mer and seed records (see the top of the file): *on = 1 when every rank scans all
+// positions and keeps its own records -- the caller then moves NOTHING after the KMERS and SEED stages (their records are in the
+// receive slots already) -- 0 when the caller runs the all-to-all.  set >= 0 overrides the choice cora_hip_shard_begin made
+// (all ranks must agree; before the KMERS stage).
+extern "C" int cora_hip_shard_filter(cora_hip_job *job, int set, int *on)
+{
+    if (!job || !job->shard) return fail(19, "cora_hip_shard_begin has not run");
+    if (set >= 0) job->shard->filter = job->shard->world > 1 && set != 0;
+    if (on) *on = job->shard->filter ? 1 : 0;
     return 0;
 }
 

@@ -1,8 +1,9 @@
 """Multi-GPU table build: one process per GPU, ``torch.distributed`` moves the records.
 
 The per-rank compute is libcora_hip.so's sharded stages (cora_amd/csrc/shard.hip); this module is the
-exchange plumbing between them: ``all_to_all_single`` of K-mer records by key-hash range, of seed records
-by code hash, of directed items by source interval, a sum ``all_reduce`` of the position bitmap of later class
+exchange plumbing between them: ``all_to_all_single`` of K-mer records by key-hash range and of seed records
+by code hash (above 4 ranks; up to 4 every rank scans all positions itself and keeps the records it owns, because a
+GPU pair has one xGMI link: ``cora_hip_shard_filter``), of directed items by source interval, a sum ``all_reduce`` of the position bitmap of later class
 members (bits are disjoint, so sum = or) and of per-position item counts near the interval starts, a min
 ``all_reduce`` of the first-singleton key, and gathers to rank 0 for the two final tables.  With the
 ``nccl`` backend (= RCCL over xGMI) tensors stay in HBM; with ``gloo`` (CPU rehearsal of the same code
@@ -91,8 +92,10 @@ class Comm:
 class ShardedJob:
     """Drives one sharded table build; every rank calls run(); rank 0 ends up with the tables."""
 
-    def __init__(self, job: hip.Job, comm: Comm):
+    def __init__(self, job: hip.Job, comm: Comm, filter=None):
         self.job, self.comm = job, comm
+        self.filter = filter          # None: the library's choice (world <= 4, CORA_SHARD_FILTER); True / False: forced
+        self.kept_own = False         # what the last run did
         self.lib = hip.lib()
         self.h = job._h
 
@@ -158,8 +161,18 @@ class ShardedJob:
         c, lib, h = self.comm, self.lib, self.h
         torch.cuda.synchronize()
         hip._check(lib.cora_hip_shard_begin(h, c.rank, c.world))
+        # K-mer and seed records reach their owner by all-to-all, or -- 2 to 4 ranks, where a GPU pair has one xGMI link
+        # (shard.hip) -- every rank scans all positions and keeps its own, and nothing is moved.  The ranks must agree.
+        on = C.c_int()
+        hip._check(lib.cora_hip_shard_filter(h, -1 if self.filter is None else int(self.filter), C.byref(on)))
+        keep_own = bool(c.all_reduce_min_int(on.value))
+        if keep_own != bool(on.value):
+            hip._check(lib.cora_hip_shard_filter(h, int(keep_own), C.byref(on)))
+        self.kept_own = keep_own
         # exact: K-mer records to the owner of their hash range
-        self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], self._stage(ST_KMERS))
+        counts = self._stage(ST_KMERS)
+        if not keep_own:
+            self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], counts)
         self._stage(ST_EXACT)
         key = C.c_uint64()
         hip._check(lib.cora_hip_shard_get_first_singleton(h, C.byref(key)))
@@ -181,7 +194,8 @@ class ShardedJob:
             hip._check(lib.cora_hip_shard_seed_sketch(h, C.byref(on)))
             if on.value:                                  # large references: the records' sketches travel along (same answer on every rank)
                 pairs.append((SLOT_SEND_B, SLOT_RECV_B))
-            self._route(pairs, counts)
+            if not keep_own:
+                self._route(pairs, counts)
             self._stage(ST_VERIFY, seed)
         # lists are finished by the owner of their source position; intervals are cut where a position holds no list
         self._stage(ST_ITEMS)

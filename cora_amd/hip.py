@@ -23,7 +23,7 @@ EXPORTS = [
     "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_run_multi", "cora_hip_device_count", "cora_hip_job_tables", "cora_hip_job_stats",
     "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers", "cora_hip_test_window_bits",
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
-    "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_seed_sketch", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
+    "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_seed_sketch", "cora_hip_shard_filter", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
     "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
     "cora_hip_tables_export", "cora_hip_tables_lookup_equiv", "cora_hip_tables_destroy",
     "cora_hip_fasta_scan", "cora_hip_fasta_get_info", "cora_hip_fasta_fai_text", "cora_hip_fasta_contig",
@@ -140,6 +140,7 @@ def lib():
         L.cora_hip_shard_slot_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cora_hip_shard_slot_reserve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
         L.cora_hip_shard_seed_sketch.argtypes = [C.c_void_p, C.c_void_p]
+        L.cora_hip_shard_filter.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cora_hip_shard_get_first_singleton.argtypes = [C.c_void_p, C.c_void_p]
         L.cora_hip_shard_set_first_singleton.argtypes = [C.c_void_p, C.c_uint64]
         L.cora_hip_tables_load.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint64,

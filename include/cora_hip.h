@@ -141,6 +141,12 @@ int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const void *src_devi
 int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t n_elems, void **ptr);
 /* After a SEED stage: 1 if the seed records carry sketches, i.e. SEND_B / RECV_B must be moved like SEND_A / RECV_A (same answer on every rank). */
 int cora_hip_shard_seed_sketch(cora_hip_job *job, int *on);
+/* How the K-mer and seed records reach their owner in this build (chosen by cora_hip_shard_begin: world <= 4, or
+ * CORA_SHARD_FILTER=0/1).  *on = 0: the caller moves SEND_* to RECV_* by all-to-all after the KMERS and SEED stages.
+ * *on = 1: every rank scanned ALL positions itself and kept the records it owns -- they are in RECV_* when the stage returns
+ * and nothing is moved (a GPU pair shares one xGMI link: on 2 or 4 GPUs the all-to-all costs more than the extra scan).
+ * set >= 0 overrides the choice (before the KMERS stage; every rank the same).  No counterpart in the reference. */
+int cora_hip_shard_filter(cora_hip_job *job, int set, int *on);
 int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
 int cora_hip_shard_set_first_singleton(cora_hip_job *job, uint64_t key);
 

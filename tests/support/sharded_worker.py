@@ -22,7 +22,10 @@ for name in os.environ["CORA_TEST_CASES"].split(","):
     c, want = helpers.golden_case(name)
     job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
     job.set_reference_file(helpers.input_path(c["input"]))
-    cdist.ShardedJob(job, comm).run()
+    sj = cdist.ShardedJob(job, comm)
+    sj.run()
+    if rank == 0:
+        open(os.path.join(os.environ["CORA_TEST_OUT"], name + ".kept_own"), "w").write(str(int(sj.kept_own)))
     if rank > 0:                                   # a later rank keeps the bytes of its own source interval
         open(os.path.join(os.environ["CORA_TEST_OUT"], "%s.rank%d.bytes" % (name, rank)), "w").write(str(len(job.tables()[2])))
     if rank == 0:

@@ -29,11 +29,17 @@ def test_sharded_world1_equals_reference(name):
     job.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_ranks_over_gloo_equal_reference(world, tmp_path):
+@pytest.mark.parametrize("world,keep_own", [(2, None), (3, None), (2, "0"), (3, "0"), (5, "1")])
+def test_sharded_ranks_over_gloo_equal_reference(world, keep_own, tmp_path):
+    """keep_own: how the K-mer and seed records reach their owner (shard.hip) -- None = the library's choice (2 to 4 ranks:
+    every rank scans everything and keeps its own), "0" = the all-to-all forced, "1" = keeping forced at a world that
+    would exchange."""
     script = os.path.join(helpers.ROOT, "tests", "support", "sharded_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world), CORA_TEST_CASES=",".join(CASES),
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world + (10 if keep_own else 0)), CORA_TEST_CASES=",".join(CASES),
                CORA_TEST_OUT=str(tmp_path))
+    env.pop("CORA_SHARD_FILTER", None)
+    if keep_own is not None:
+        env["CORA_SHARD_FILTER"] = keep_own
     if world == 3:
         env["CORA_SKETCH"] = "1"       # the seed records carry sketches (what a large reference switches on): one more slot to move
     procs = [subprocess.Popen([sys.executable, script, str(r), str(world)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -48,6 +54,9 @@ def test_sharded_ranks_over_gloo_equal_reference(world, tmp_path):
     # the <Inexact> stage really was split: every later rank wrote part of the big case's table
     for r in range(1, world):
         assert int(open(os.path.join(str(tmp_path), "ecoli_like_k50_d2.rank%d.bytes" % r)).read()) > 0
+    # and the records came the way the test asked for
+    want_kept = (world <= 4) if keep_own is None else keep_own == "1"
+    assert open(os.path.join(str(tmp_path), "ecoli_like_k50_d2.kept_own")).read().strip() == str(int(want_kept))
 
 
 def test_rccl_collectives_single_rank():
@@ -65,12 +74,16 @@ def test_rccl_collectives_single_rank():
 
 
 # ------------------------------------------------------------------ the same flow inside ONE process (cora_hip_job_run_multi)
-@pytest.mark.parametrize("world,sketch", [(1, None), (2, None), (3, "1"), (8, None), (8, "1")])
-def test_in_process_ranks_equal_reference(world, sketch, monkeypatch):
+@pytest.mark.parametrize("world,sketch,keep_own", [(1, None, None), (2, None, None), (2, None, "0"), (3, "1", None), (3, "1", "0"), (4, None, None),
+                                                   (8, None, None), (8, "1", None), (8, "1", "1"), (8, None, "1")])
+def test_in_process_ranks_equal_reference(world, sketch, keep_own, monkeypatch):
     """One host thread per rank, records pulled rank to rank by device copies: the flow the executable runs on a node with
     several GPUs, rehearsed with every rank on the one GPU.  Same bytes as the reference, same whole-job counts as the
-    single-GPU run, on two calls in a row (the ranks' replicas are kept between calls)."""
+    single-GPU run, on two calls in a row (the ranks' replicas are kept between calls).  keep_own as in the test above."""
     hip.init(0)
+    monkeypatch.delenv("CORA_SHARD_FILTER", raising=False)
+    if keep_own is not None:
+        monkeypatch.setenv("CORA_SHARD_FILTER", keep_own)
     if sketch:
         monkeypatch.setenv("CORA_SKETCH", sketch)      # sketches travel with the seed records, as on a large reference
     for name in CASES:
