@@ -220,14 +220,25 @@ struct Rank {
         static const int rx_parts[4] = {CORA_SLOT_RX_CLS, CORA_SLOT_RX_CNT, CORA_SLOT_RX_ENT, CORA_SLOT_RX_DIR};
         static const int f2[1] = {CORA_SLOT_F2}, rx_f2[1] = {CORA_SLOT_RX_F2};
 
+        // CORA_TRACE: rank 0 prints the wall time of each part of the flow (the other ranks are inside the same barriers)
+        const bool trace = r == 0 && getenv("CORA_TRACE");
+        auto t_last = std::chrono::steady_clock::now();
+        auto mark = [&](const char *what) {
+            if (!trace) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[cora] ranks: %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
         TRY(cora_hip_shard_begin(job, r, world));
         if (!sync()) return;
+        mark("pack");
         // exact: K-mer records to the owner of their hash range -- by all-to-all, or (2 to 4 ranks: shard.hip) every rank scans all
         // positions and keeps its own; the same choice on every rank (same world, same environment)
         int filter = 0;
         TRY(cora_hip_shard_filter(job, -1, &filter));
         if (filter) TRY(cora_hip_shard_stage(job, CORA_ST_KMERS, 0, nullptr));
         else if (!all_to_all(CORA_ST_KMERS, 0, send_ac, recv_ac, eb_rec, 2)) return;
+        mark("k-mer records");
         TRY(cora_hip_shard_stage(job, CORA_ST_EXACT, 0, nullptr));
         TRY(cora_hip_shard_get_first_singleton(job, &t.pub[r].value));
         if (!sync()) return;
@@ -236,10 +247,14 @@ struct Rank {
             for (int q = 0; q < world; q++) m = t.pub[q].value < m ? t.pub[q].value : m;
             TRY(cora_hip_shard_set_first_singleton(job, m));
         }
+        mark("exact classes");
         if (!all_reduce_u32(CORA_SLOT_REPMASK, true)) return;              // later class members: disjoint bits
+        mark("bitmap all-reduce");
         TRY(cora_hip_shard_stage(job, CORA_ST_PARTS, 0, nullptr));
         if (!gather_to_root(x_parts, rx_parts, eb_parts, 4)) return;
+        mark("class parts to rank 0");
         if (r == 0) TRY(cora_hip_shard_stage(job, CORA_ST_MERGE, 0, nullptr));
+        mark("exact table (rank 0)");
         // inexact: seed records to the owner of their code hash, verification there
         TRY(cora_hip_shard_stage(job, CORA_ST_REPS, 0, nullptr));
         // (large references: the records' sketches travel with them -- every rank takes the same decision from the reference's size)
@@ -249,14 +264,19 @@ struct Rank {
         for (int seed = 1; seed <= job->dp.nseeds; seed++) {
             if (filter) TRY(cora_hip_shard_stage(job, CORA_ST_SEED, seed, nullptr));
             else if (!(sketched ? all_to_all(CORA_ST_SEED, seed, send_ab, recv_ab, eb_code2, 2) : all_to_all(CORA_ST_SEED, seed, send_a, recv_a, eb_code, 1))) return;
+            mark("seed records");
             TRY(cora_hip_shard_stage(job, CORA_ST_VERIFY, seed, nullptr));
+            mark("seed sort + verification");
         }
         // lists are finished by the owner of their source position; intervals are cut where a position holds no list
         TRY(cora_hip_shard_stage(job, CORA_ST_ITEMS, 0, nullptr));
         if (!sync()) return;
         if (world > 1 && !all_reduce_u32(CORA_SLOT_WCOUNT, false)) return;
+        mark("items + window counts");
         if (!all_to_all(CORA_ST_ITEM_CUT, 0, send_ac, recv_ac, eb_rec, 2)) return;
+        mark("items to their owners");
         TRY(cora_hip_shard_stage(job, CORA_ST_FINISH, 0, nullptr));
+        mark("lists + own table bytes");
         // the counts, summed on the host; rank 0 imports the sums
         if (!t.failed.load()) {
             void *sp = nullptr;
@@ -275,6 +295,7 @@ struct Rank {
             if (rc_) fail_with(rc_);
         }
         sync();
+        mark("table bytes to rank 0");
     }
 #undef TRY
 };

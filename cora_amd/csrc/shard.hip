@@ -300,8 +300,10 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         cora_hip_stats &st = job->stats;
         st.exact_nodes = sh.fst.exact_nodes; st.inexact_nodes = sh.fst.inexact_nodes;
         st.dirty_nodes = sh.fst.dirty_nodes; st.big_nodes = sh.fst.big_nodes;
-        // this rank's bytes and counts, for the gather / the sum
-        sh.n_f2 = job->inexact_bytes.size();
+        // this rank's bytes and counts, for the gather / the sum.  Rank 0's own bytes are the head of the table and are in its
+        // host buffer already: they stay there (COLLECT puts the other ranks' bytes behind them) and do not make the round
+        // trip through the device
+        sh.n_f2 = sh.rank == 0 ? 0 : job->inexact_bytes.size();
         RCQ(sh.f2_dev.alloc(sh.n_f2)); RCQ(sh.stat_dev.alloc(N_STATS));
         if (sh.n_f2) HIPQ(hipMemcpyAsync(sh.f2_dev.p, job->inexact_bytes.data(), sh.n_f2, hipMemcpyHostToDevice, s));
         const u64 hs[N_STATS] = {st.inexact_nodes, st.dirty_nodes, st.big_nodes, st.inexact_items, st.hom_pairs, st.candidate_pairs, 0, 0};
@@ -316,12 +318,19 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     }
     case ST_COLLECT: {                  // rank 0: the table is the ranks' byte ranges in rank order; counts are the sums
         cora_hip_stats &st = job->stats;
-        if (!job->inexact_bytes.reserve_uninit(sh.n_f2_all + 16)) return fail(101, "host allocation of %llu bytes for <Inexact> failed", (unsigned long long)sh.n_f2_all + 16);
-        if (sh.n_f2_all) HIPQ(hipMemcpyAsync(job->inexact_bytes.p, sh.f2_all.p, sh.n_f2_all, hipMemcpyDeviceToHost, s));
+        ByteBuf &tb = job->inexact_bytes;
+        const size_t own = tb.size(), total = own + sh.n_f2_all;
+        if (!tb.p || tb.cap < total + 16) {             // (first build of a job only: later ones find the room of the last table)
+            ByteBuf grown;
+            if (!grown.reserve_uninit(total + 16)) return fail(101, "host allocation of %llu bytes for <Inexact> failed", (unsigned long long)total + 16);
+            if (own) memcpy(grown.p, tb.p, own);
+            std::swap(tb.p, grown.p); std::swap(tb.cap, grown.cap); std::swap(tb.mapped, grown.mapped);
+        }
+        if (sh.n_f2_all) HIPQ(hipMemcpyAsync(tb.p + own, sh.f2_all.p, sh.n_f2_all, hipMemcpyDeviceToHost, s));
         u64 hs[N_STATS] = {0};
         if (sh.stat_dev.p) HIPQ(hipMemcpyAsync(hs, sh.stat_dev.p, sizeof hs, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
-        job->inexact_bytes.n = sh.n_f2_all;
+        tb.n = total;
         st.inexact_nodes = hs[0]; st.dirty_nodes = hs[1]; st.big_nodes = hs[2]; st.inexact_items = hs[3]; st.hom_pairs = hs[4];
         st.candidate_pairs = hs[5];
         sh.f2_all.release(); sh.f2_dev.release();
