@@ -252,12 +252,15 @@ struct PairStore {
 
 int st_pack(cora_hip_job *job);
 int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out);
-int st_exact_classes(cora_hip_job *job, ExactLocal &x);
+int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from = nullptr);
+inline int exact_sort_bits(const cora_hip_job *job) { return job->hash_bits ? job->hash_bits : 40; }     // the exact sort runs on the top bits of the hash
+inline int seed_sort_lo(bool with_sketch) { return with_sketch ? 96 : 32; }                             // a seed record's code: 32 bits from here
 int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p);
 int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &host_ms);
 int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBuf<u32> &reps, u64 &n_out);
 int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist = nullptr,
-                   u64 *sk_b = nullptr, u32 *sk_c = nullptr /* [n] per-record sketches for k_verify's pre-filter; sorted along */);
+                   u64 *sk_b = nullptr, u32 *sk_c = nullptr /* [n] per-record sketches for k_verify's pre-filter; sorted along */,
+                   const SortSource *from = nullptr);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
 void multi_state_free(cora_hip_job *job);

@@ -49,9 +49,11 @@ __device__ __forceinline__ u32 rs_digit(u64 word, int shift, u32 mask, u32 dmode
     return (u32)(((u64)top * world) >> 32);
 }
 
+// fmode != 0: only the records whose owner (rs_digit with dmode = fmode) is `fme` are counted -- the first pass of a sort
+// that reads ALL records of a multi-GPU build and keeps this rank's (radix_sort's SortSource).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u64 n, int shift, u32 mask,
-                                                    u32 *__restrict__ tile_hist, u32 dmode, u32 world)
+                                                    u32 *__restrict__ tile_hist, u32 dmode, u32 world, u32 fmode, u32 fme)
 {
     constexpr int RS_THREADS = THREADS, RS_TILE = THREADS * RS_IPT;
     __shared__ u32 h[256];
@@ -66,14 +68,17 @@ __global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u6
         for (int k = 0; k < RS_IPT / 2; k++) { v[k].x = __builtin_nontemporal_load(&w2[k * RS_THREADS + tid].x); v[k].y = __builtin_nontemporal_load(&w2[k * RS_THREADS + tid].y); }
 #pragma unroll
         for (int k = 0; k < RS_IPT / 2; k++) {
-            atomicAdd(&h[rs_digit(v[k].x, shift, mask, dmode, world)], 1u);
-            atomicAdd(&h[rs_digit(v[k].y, shift, mask, dmode, world)], 1u);
+            if (!fmode || rs_digit(v[k].x, 0, 0, fmode, world) == fme) atomicAdd(&h[rs_digit(v[k].x, shift, mask, dmode, world)], 1u);
+            if (!fmode || rs_digit(v[k].y, 0, 0, fmode, world) == fme) atomicAdd(&h[rs_digit(v[k].y, shift, mask, dmode, world)], 1u);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < RS_IPT; k++) {
             u64 idx = base + (u64)k * RS_THREADS + tid;
-            if (idx < n) atomicAdd(&h[rs_digit(w[idx], shift, mask, dmode, world)], 1u);
+            if (idx < n) {
+                const u64 v = w[idx];
+                if (!fmode || rs_digit(v, 0, 0, fmode, world) == fme) atomicAdd(&h[rs_digit(v, shift, mask, dmode, world)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u6
 // Loads are issued in batches of independent loads before anything is stored: these kernels are latency-bound.
 constexpr int RS_BATCH = 16;
 
-__global__ __launch_bounds__(256) void rs_colsum(const u32 *__restrict__ tile_hist, u32 tiles, u32 *__restrict__ chunk_sums)
+__global__ __launch_bounds__(256) void rs_colsum(const u32 *__restrict__ tile_hist, u32 tiles, u32 *__restrict__ chunk_sums,
+                                                  unsigned long long *__restrict__ grand_total /* may be null: + all counts of this chunk */)
 {
     const u32 t0 = blockIdx.x * RS_CHUNK_TILES;
     const u32 t1 = min(tiles, t0 + RS_CHUNK_TILES);
@@ -100,6 +106,15 @@ __global__ __launch_bounds__(256) void rs_colsum(const u32 *__restrict__ tile_hi
         for (int i = 0; i < RS_BATCH; i++) s += v[i];
     }
     chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+    if (grand_total) {                               // (one atomic per chunk of 64 tiles)
+        __shared__ u32 ws[4];
+        u32 x = s;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(grand_total, (unsigned long long)ws[0] + ws[1] + ws[2] + ws[3]);
+    }
 }
 
 // 1024 threads: thread (q, d) scans quarter q of the chunks for digit d; chunk_off[c][d] = digit base + counts in chunks < c
@@ -173,15 +188,16 @@ __global__ __launch_bounds__(256) void rs_colscan(u32 *tile_hist, u32 tiles, con
 // The scatter.  Thread (wave w, lane l) owns records base + w*64*IPT + r*64 + l, r = 0..IPT-1,
 // so that (wave, round, lane) order is the input order: ranks assigned in that order keep
 // the sort stable.
-template <bool HAS_B, bool HAS_C, bool DIG_B, int THREADS>
+template <bool HAS_B, bool HAS_C, bool DIG_B, int THREADS, bool FILTER>
 __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_in, const u64 *__restrict__ b_in,
                                                           const u32 *__restrict__ c_in, u64 *__restrict__ a_out,
                                                           u64 *__restrict__ b_out, u32 *__restrict__ c_out, u64 n,
                                                           int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg, u32 dmode, u32 world,
-                                                          u32 keep)
+                                                          u32 fmode, u32 fme)
 {
-    // keep != RS_KEEP_ALL: only the records of digit `keep` are written, packed from index 0 of the output arrays (the
-    // multi-GPU flow's "scan everything, keep what I own": radix_partition_move)
+    // FILTER: the tile is read whole, but only the records whose owner (rs_digit with dmode = fmode) is `fme` are ranked,
+    // staged and written -- the first pass of a sort over ALL records of a multi-GPU build that keeps this rank's
+    // (SortSource); tile_off then holds the offsets of the kept records only.
     constexpr int RS_THREADS = THREADS, RS_TILE = THREADS * RS_IPT, RS_WAVES = THREADS / 64;
     __shared__ u64 stage[RS_TILE];          // 8 B per record of the tile
     __shared__ u32 wcnt[RS_WAVES][256];            // per-wave digit counters, then per-wave digit bases
@@ -232,10 +248,15 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
     __syncthreads();
 
     u32 lpos[RS_IPT];
+    u32 vmask = 0;                          // FILTER: which of this thread's records are kept
     const u64 lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
-        const bool valid = (l0 + r * 64) < count;
+        bool valid = (l0 + r * 64) < count;
+        if (FILTER) {
+            valid = valid && rs_digit(kw[r], 0, 0, fmode, world) == fme;
+            vmask |= valid ? (1u << r) : 0u;
+        }
         const u32 d = rs_digit(kw[r], shift, mask, dmode, world);
         u64 peers = __ballot(valid);
 #pragma unroll
@@ -254,25 +275,27 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    u32 staged = count;                     // records of this tile that are written (FILTER: the kept ones)
     {
         // threads 0..255 own one digit each: per-wave counts -> per-wave starts inside the tile
         const int dg = tid & 255;
         u32 c[RS_WAVES], tot = 0;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; w++) { c[w] = wcnt[w][dg]; tot += c[w]; }
-        const u32 start = block_exclusive_scan_256(tid < 256 ? tot : 0u, wsum, nullptr);
+        u32 kept = 0;
+        const u32 start = block_exclusive_scan_256(tid < 256 ? tot : 0u, wsum, FILTER ? &kept : nullptr);
+        if (FILTER) staged = kept;
         if (tid < 256) {
             u32 run = start;
 #pragma unroll
             for (int w = 0; w < RS_WAVES; w++) { wcnt[w][dg] = run; run += c[w]; }
-            // (row 0 of the scanned histogram = where each digit's records begin: the kept digit's output starts at 0)
-            delta[tid] = tile_off[(size_t)tile * 256 + tid] - start - (keep != RS_KEEP_ALL ? tile_off[keep] : 0u);
+            delta[tid] = tile_off[(size_t)tile * 256 + tid] - start;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
-        if ((l0 + r * 64) < count) {
+        if (FILTER ? ((vmask >> r) & 1u) != 0 : (l0 + r * 64) < count) {
             const u32 d = rs_digit(kw[r], shift, mask, dmode, world);
             lpos[r] += wcnt[wv][d];
             stage[lpos[r]] = kw[r];
@@ -294,14 +317,10 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
     for (int k = 0; k < RS_IPT; k++) {
         const u32 i = k * RS_THREADS + tid;
-        dst[k] = RS_KEEP_ALL;                 // (no record goes to index 2^32 - 1: n < 2^32)
-        if (i < count) {
+        if (i < staged) {
             const u64 v = stage[i];
-            const u32 dg = rs_digit(v, shift, mask, dmode, world);
-            if (keep == RS_KEEP_ALL || dg == keep) {
-                dst[k] = delta[dg] + i;
-                dig_out[dst[k]] = v;
-            }
+            dst[k] = delta[rs_digit(v, shift, mask, dmode, world)] + i;
+            dig_out[dst[k]] = v;
         }
     }
     if (HAS_B) {
@@ -309,13 +328,13 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            if (li < count) stage[lpos[r]] = PRE_B ? ov[r] : lv[r];
+            if (FILTER ? ((vmask >> r) & 1u) != 0 : li < count) stage[lpos[r]] = PRE_B ? ov[r] : lv[r];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RS_IPT; k++) {
             const u32 i = k * RS_THREADS + tid;
-            if (i < count && dst[k] != RS_KEEP_ALL) oth_out[dst[k]] = stage[i];
+            if (i < staged) oth_out[dst[k]] = stage[i];
         }
     }
     if (HAS_C) {
@@ -324,13 +343,13 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            if (li < count) stage32[lpos[r]] = cv[r];
+            if (FILTER ? ((vmask >> r) & 1u) != 0 : li < count) stage32[lpos[r]] = cv[r];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RS_IPT; k++) {
             const u32 i = k * RS_THREADS + tid;
-            if (i < count && dst[k] != RS_KEEP_ALL) c_out[dst[k]] = stage32[i];
+            if (i < staged) c_out[dst[k]] = stage32[i];
         }
     }
 }
@@ -351,7 +370,7 @@ int SortScratch::reserve(u64 n)
     if (chunks > cap_chunks) {
         if (chunk_sums) (void)hipFree(chunk_sums);
         chunk_sums = nullptr; cap_chunks = 0;
-        RS_CHECK(hipMalloc(&chunk_sums, 2 * chunks * 256 * sizeof(u32)));     // sums, then offsets
+        RS_CHECK(hipMalloc(&chunk_sums, (2 * chunks * 256 + 2) * sizeof(u32)));     // sums, then offsets, then one 8-byte total (radix_sort_count_kept)
         cap_chunks = chunks;
     }
     if (!xcd_group) {
@@ -381,27 +400,90 @@ void SortScratch::release()
 
 template <bool HAS_B, bool HAS_C>
 static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
-                           int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0, u32 keep = RS_KEEP_ALL)
+                           int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0, u32 fmode = 0, u32 fme = 0)
 {
     constexpr int T = (HAS_C || HAS_B) ? 512 : 256;
-    if (HAS_B && dig_b)
-        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg, dmode, world, keep);
+    if (fmode)                              // (the filtered first pass of a sort: the digit word is a)
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T, true>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+    else if (HAS_B && dig_b)
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, T, false>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, 0u, 0u);
     else
-        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg, dmode, world, keep);
+        hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T, false>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, 0u, 0u);
+}
+
+static void launch_scatter_any(hipStream_t s, bool has_b, bool has_c, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
+                               int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0, u32 fmode = 0, u32 fme = 0)
+{
+    if (has_b) {
+        if (has_c) launch_scatter<true, true>(s, dig_b, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+        else launch_scatter<true, false>(s, dig_b, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+    } else {
+        if (has_c) launch_scatter<false, true>(s, false, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+        else launch_scatter<false, false>(s, false, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+    }
+}
+
+static void launch_hist(hipStream_t s, bool wide, u32 tiles, const u64 *word, u64 n, int shift, u32 mask, u32 *th, u32 dmode = 0, u32 world = 0,
+                        u32 fmode = 0, u32 fme = 0)
+{
+    if (wide) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th, dmode, world, fmode, fme);
+    else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th, dmode, world, fmode, fme);
+}
+
+static void launch_offsets(hipStream_t s, u32 *th, u32 tiles, SortScratch &scratch, unsigned long long *grand_total = nullptr)
+{
+    const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
+    hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums, grand_total);
+    u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
+    hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);
+    hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, th, tiles, chunk_off);
+}
+
+// The first half of a sort whose first pass reads ALL records of a multi-GPU build and keeps this rank's (SortSource):
+// histogram of the first digit over the kept records + offsets, left in scratch.tile_hist; *n_kept = how many records the
+// sort will hold (the caller sizes keys / tmp from it, then calls radix_sort with the same bit range and `from`).
+int radix_sort_count_kept(hipStream_t s, const SortSource &from, int bit_lo, int bit_hi, SortScratch &scratch, u64 *n_kept)
+{
+    *n_kept = 0;
+    if (from.n == 0) return 0;
+    if (from.n >= (1ull << 32) || (from.fmode != 1 && from.fmode != 2) || from.world < 1 || from.world > 256 || from.me >= from.world || bit_hi <= bit_lo)
+        return (int)hipErrorInvalidValue;
+    bit_lo &= ~7;
+    int rc = scratch.reserve(from.n);
+    if (rc) return rc;
+    const bool has_b = from.src.b != nullptr, has_c = from.src.c != nullptr;
+    if (has_b && bit_lo < 64) return (int)hipErrorInvalidValue;         // the owner is read from word a: it must be the digit word too
+    const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
+    const u32 tiles = (u32)((from.n + tile_recs - 1) / tile_recs);
+    const int nbits = (bit_hi - bit_lo) < 8 ? (bit_hi - bit_lo) : 8;
+    const int shift = has_b ? (bit_lo & 63) : bit_lo;
+    if (scratch.external) return (int)hipErrorInvalidValue;             // (a caller-provided scratch has no room for the total)
+    unsigned long long *total_dev = reinterpret_cast<unsigned long long *>(scratch.chunk_sums + 2 * scratch.cap_chunks * 256);
+    RS_CHECK(hipMemsetAsync(total_dev, 0, sizeof(unsigned long long), s));
+    launch_hist(s, has_b || has_c, tiles, from.src.a, from.n, shift, (1u << nbits) - 1u, scratch.tile_hist, 0u, from.world, (u32)from.fmode, from.me);
+    launch_offsets(s, scratch.tile_hist, tiles, scratch, total_dev);
+    unsigned long long h = 0;
+    RS_CHECK(hipMemcpyAsync(&h, total_dev, sizeof h, hipMemcpyDeviceToHost, s));
+    RS_CHECK(hipStreamSynchronize(s));
+    *n_kept = h;
+    RS_CHECK(hipGetLastError());
+    return 0;
 }
 
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi, SortScratch &scratch,
-               SortTiming *timing, u32 *first_hist)
+               SortTiming *timing, u32 *first_hist, const SortSource *from)
 {
     if (n == 0 || bit_hi <= bit_lo) return 0;
     if (n >= (1ull << 32)) return (int)hipErrorInvalidValue;      // u32 offsets inside the kernels
     bit_lo &= ~7;
     if ((bit_hi - bit_lo + 7) / 8 > RS_MAX_PASSES) return (int)hipErrorInvalidValue;
+    if (from && (first_hist || from->n < n)) return (int)hipErrorInvalidValue;
     const bool timed = timing && timing->enabled;
     int pass = 0;
-    int rc = scratch.reserve(n);
+    int rc = scratch.reserve(from ? from->n : n);                  // (never shrinks: what radix_sort_count_kept left is still there)
     if (rc) return rc;
     if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
     // records with a 4-byte payload go through 512-thread tiles of 8192 (their payload runs are twice as long: +9 % scatter
@@ -409,11 +491,11 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     // through 256-thread tiles of 4096: two-word records need 140 VGPRs, which leaves 512-thread workgroups one per CU
     // (measured at 2.9e9 records: 30.3 ms per pass against 27.1).  1024-thread tiles of 16384 (one workgroup per CU, runs
     // twice as long) were slower still: 21.9 ms per pass against 20.4 at 2.6e9 two-word records
-    const u32 tile_recs = radix_sort_tile_records(keys.b != nullptr, keys.c != nullptr);
-    const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
-    const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
     const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
+    const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
+    const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
     const u64 rec_bytes = 8 + (has_b ? 8 : 0) + (has_c ? 4 : 0);
+    u64 moved[RS_MAX_PASSES];
     for (int bit = bit_lo; bit < bit_hi; bit += 8, pass++) {
         const int nbits = (bit_hi - bit) < 8 ? (bit_hi - bit) : 8;
         const u32 mask = (1u << nbits) - 1u;
@@ -421,22 +503,24 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const int shift = has_b ? (bit & 63) : bit;
         const u64 *word = dig_b ? keys.b : keys.a;
         u32 *th = scratch.tile_hist;
-        if (pass == 0 && first_hist) th = first_hist;                    // the producer already counted this digit (tiles of radix_sort_tile_records())
-        else if (has_c || has_b) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th, 0u, 0u);
-        else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th, 0u, 0u);
-        hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums);
-        u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
-        hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);
-        hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, th, tiles, chunk_off);
-        if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass], s));
-        if (has_b) {
-            if (has_c) launch_scatter<true, true>(s, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
-            else launch_scatter<true, false>(s, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
-        } else {
-            if (has_c) launch_scatter<false, true>(s, false, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
-            else launch_scatter<false, false>(s, false, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
+        if (pass == 0 && from) {
+            // the kept records' offsets are in scratch.tile_hist already (radix_sort_count_kept, same bit range); the pass reads
+            // the whole source and writes this rank's records, so what follows works on n records
+            const u32 tiles0 = (u32)((from->n + tile_recs - 1) / tile_recs);
+            if (timed) RS_CHECK(hipEventRecord(scratch.ev[0], s));
+            launch_scatter_any(s, has_b, has_c, false, tiles0, from->src, tmp, from->n, shift, mask, th, scratch.xcd_group, 0u, from->world, (u32)from->fmode, from->me);
+            if (timed) RS_CHECK(hipEventRecord(scratch.ev[1], s));
+            moved[0] = rec_bytes * (from->n + n);
+            SortArrays t0 = keys; keys = tmp; tmp = t0;
+            continue;
         }
+        if (pass == 0 && first_hist) th = first_hist;                    // the producer already counted this digit (tiles of radix_sort_tile_records())
+        else launch_hist(s, has_c || has_b, tiles, word, n, shift, mask, th);
+        launch_offsets(s, th, tiles, scratch);
+        if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass], s));
+        launch_scatter_any(s, has_b, has_c, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
         if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass + 1], s));
+        moved[pass] = 2 * rec_bytes * n;
         SortArrays t = keys; keys = tmp; tmp = t;
     }
     if (timed) {                                                   // read the events once, after the last pass
@@ -446,7 +530,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
             RS_CHECK(hipEventElapsedTime(&ms, scratch.ev[2 * q], scratch.ev[2 * q + 1]));
             timing->scatter_ms += ms;
             timing->scatter_launches += 1;
-            timing->scatter_bytes += 2 * rec_bytes * n;
+            timing->scatter_bytes += moved[q];
         }
     }
     RS_CHECK(hipGetLastError());
@@ -454,57 +538,28 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
 }
 
 // One stable pass that groups the records by the rank that owns them (rs_digit, dmode 1 or 2): the multi-GPU flow's
-// partition.  Every array of the record moves in this one pass; the digit comes from keys.a.  Two calls, because the
-// caller sizes the output from the counts:
-//   radix_partition_count   histogram + offsets; counts[r] = records of rank r (synchronises the stream)
-//   radix_partition_move    the scatter, straight after the count on the same arrays.  keep < 0: all n records, grouped by
-//                           rank, into `out`; keep = r: only rank r's records, packed from index 0 (out holds counts[r]).
-int radix_partition_count(hipStream_t s, const SortArrays &keys, u64 n, int dmode, u32 world, SortScratch &scratch, uint64_t *counts)
+// partition before an exchange.  Every array of the record moves in this one pass; the digit comes from keys.a.
+// counts[r] = records of rank r.  The result is in `keys` (the arrays are swapped, as in radix_sort).
+int radix_partition(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int dmode, u32 world, SortScratch &scratch, SortTiming *timing,
+                    uint64_t *counts)
 {
     for (u32 r = 0; r < world; r++) counts[r] = 0;
     if (n == 0) return 0;
     if (n >= (1ull << 32) || world < 1 || world > 256 || (dmode != 1 && dmode != 2)) return (int)hipErrorInvalidValue;
+    const bool timed = timing && timing->enabled;
     int rc = scratch.reserve(n);
     if (rc) return rc;
-    const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
-    const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
-    const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
-    const u32 chunks = (tiles + RS_CHUNK_TILES - 1) / RS_CHUNK_TILES;
-    u32 *th = scratch.tile_hist;
-    if (has_c || has_b) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, keys.a, n, 0, 255u, th, (u32)dmode, world);
-    else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, keys.a, n, 0, 255u, th, (u32)dmode, world);
-    hipLaunchKernelGGL(rs_colsum, dim3(chunks), dim3(256), 0, s, th, tiles, scratch.chunk_sums);
-    u32 *chunk_off = scratch.chunk_sums + scratch.cap_chunks * 256;
-    hipLaunchKernelGGL(rs_chunkscan, dim3(1), dim3(1024), 0, s, scratch.chunk_sums, chunk_off, chunks);
-    hipLaunchKernelGGL(rs_colscan, dim3(chunks), dim3(256), 0, s, th, tiles, chunk_off);
-    u32 starts[256];                                                 // row of tile 0: where each rank's records begin
-    RS_CHECK(hipMemcpyAsync(starts, th, world * sizeof(u32), hipMemcpyDeviceToHost, s));
-    RS_CHECK(hipStreamSynchronize(s));
-    for (u32 r = 0; r < world; r++) counts[r] = (r + 1 < world ? starts[r + 1] : (u64)n) - starts[r];
-    RS_CHECK(hipGetLastError());
-    return 0;
-}
-
-int radix_partition_move(hipStream_t s, const SortArrays &keys, const SortArrays &out, u64 n, int dmode, u32 world, int keep, u64 n_kept,
-                         SortScratch &scratch, SortTiming *timing)
-{
-    if (n == 0) return 0;
-    if (n >= (1ull << 32) || world < 1 || world > 256 || (dmode != 1 && dmode != 2) || keep >= (int)world) return (int)hipErrorInvalidValue;
-    const bool timed = timing && timing->enabled;
     if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
     const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
     const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
     const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
-    u32 *th = scratch.tile_hist;                                     // as radix_partition_count left it
-    const u32 kp = keep < 0 ? RS_KEEP_ALL : (u32)keep;
+    u32 *th = scratch.tile_hist;
+    launch_hist(s, has_c || has_b, tiles, keys.a, n, 0, 255u, th, (u32)dmode, world);
+    launch_offsets(s, th, tiles, scratch);
+    u32 starts[256];                                                 // row of tile 0: where each rank's records begin
+    RS_CHECK(hipMemcpyAsync(starts, th, world * sizeof(u32), hipMemcpyDeviceToHost, s));
     if (timed) RS_CHECK(hipEventRecord(scratch.ev[0], s));
-    if (has_b) {
-        if (has_c) launch_scatter<true, true>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
-        else launch_scatter<true, false>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
-    } else {
-        if (has_c) launch_scatter<false, true>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
-        else launch_scatter<false, false>(s, false, tiles, keys, out, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world, kp);
-    }
+    launch_scatter_any(s, has_b, has_c, false, tiles, keys, tmp, n, 0, 255u, th, scratch.xcd_group, (u32)dmode, world);
     if (timed) RS_CHECK(hipEventRecord(scratch.ev[1], s));
     RS_CHECK(hipStreamSynchronize(s));
     if (timed) {
@@ -512,8 +567,10 @@ int radix_partition_move(hipStream_t s, const SortArrays &keys, const SortArrays
         RS_CHECK(hipEventElapsedTime(&ms, scratch.ev[0], scratch.ev[1]));
         timing->scatter_ms += ms;
         timing->scatter_launches += 1;
-        timing->scatter_bytes += (8 + (has_b ? 8 : 0) + (has_c ? 4 : 0)) * (n + (keep < 0 ? n : n_kept));     // read all, write what is kept
+        timing->scatter_bytes += 2 * (8 + (has_b ? 8 : 0) + (has_c ? 4 : 0)) * n;
     }
+    for (u32 r = 0; r < world; r++) counts[r] = (r + 1 < world ? starts[r + 1] : (u64)n) - starts[r];
+    SortArrays t = keys; keys = tmp; tmp = t;
     RS_CHECK(hipGetLastError());
     return 0;
 }

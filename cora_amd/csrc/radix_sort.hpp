@@ -53,15 +53,22 @@ constexpr int RS_CHUNK_TILES = 64;                // tiles per column-scan workg
 // computed by whoever produced the records; it is consumed (turned into offsets in place).
 u32 radix_sort_tile_records(bool has_b, bool has_c);      // records per tile for that record shape
 // One stable pass grouping the records by owning rank (multi-GPU flow): owner = (top 32 bits of keys.a [dmode 2: times the golden
-// ratio, mod 2^32]) * world >> 32.  All arrays present in `keys` move together.  _count: counts[r] = records of rank r (the caller
-// sizes `out` from them); _move, straight after it: keep < 0 writes all n records grouped by rank, keep = r only rank r's
-// records (n_kept = counts[r] of them), packed from index 0 of `out`.
-constexpr u32 RS_KEEP_ALL = 0xFFFFFFFFu;
-int radix_partition_count(hipStream_t s, const SortArrays &keys, u64 n, int dmode, u32 world, SortScratch &scratch, uint64_t *counts);
-int radix_partition_move(hipStream_t s, const SortArrays &keys, const SortArrays &out, u64 n, int dmode, u32 world, int keep, u64 n_kept,
-                         SortScratch &scratch, SortTiming *timing);
+// ratio, mod 2^32]) * world >> 32.  All arrays present in `keys` move together; counts[r] = records of rank r; result in `keys`.
+int radix_partition(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int dmode, u32 world, SortScratch &scratch, SortTiming *timing,
+                    uint64_t *counts);
+// A sort whose first pass reads ALL n records of `src` and keeps those owned by rank `me` (owner as above, fmode = dmode): the
+// multi-GPU flow on few GPUs, where every rank scans the whole reference instead of exchanging records.  First
+// radix_sort_count_kept (histogram + offsets of the first digit over the kept records; *n_kept tells the caller how big keys / tmp
+// must be), then radix_sort with the same bit range and `from`.  The digit word of the first pass must be word a.
+struct SortSource {
+    SortArrays src;
+    u64 n = 0;
+    int fmode = 1;
+    u32 world = 1, me = 0;
+};
+int radix_sort_count_kept(hipStream_t s, const SortSource &from, int bit_lo, int bit_hi, SortScratch &scratch, u64 *n_kept);
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi,
-               SortScratch &scratch, SortTiming *timing, u32 *first_hist = nullptr);
+               SortScratch &scratch, SortTiming *timing, u32 *first_hist = nullptr, const SortSource *from = nullptr);
 
 // out[i] = sum_{j<i} in[j]  (u32 in, u64 out); *total_dev (device u64) gets the grand total.
 // scratch_dev must hold at least scan_scratch_elems(n) u64.

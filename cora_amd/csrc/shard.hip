@@ -24,8 +24,9 @@
 //              and 16 B per representative and seed cross the links: fine over 7 links at once, link-bound on 2 or 4 GPUs,
 //              where a GPU pair has ONE xGMI link between them.
 //   filter     every rank holds the whole packed reference anyway: it scans ALL positions itself and keeps the records it
-//              owns (one scatter pass that writes only its own digit).  Nothing crosses a link for KMERS and SEED; the price is a
-//              scan that does not shrink with R.  Chosen for world <= 4 (CORA_SHARD_FILTER=0/1 overrides).
+//              owns -- in the first pass of the sort they are generated for, which reads all records and writes its own
+//              (radix_sort's SortSource).  Nothing crosses a link for KMERS and SEED and there is no partition pass; the price
+//              is a scan that does not shrink with R.  Chosen for world <= 4 (CORA_SHARD_FILTER=0/1 overrides).
 #include "job_internal.hpp"
 
 using namespace cora;
@@ -75,32 +76,38 @@ static void swap_buf(DBuf<T> &x, DBuf<T> &y)
     std::swap(x.p, y.p); std::swap(x.n, y.n); std::swap(x.pool, y.pool);
 }
 
-// stable partition of (a[, c][, b2]) by destination rank, all arrays in one scatter pass (radix_partition_*); counts[r] =
-// records for rank r.  mode 0: the top bits of a as they are (hash ranges), 1: hashed (seed codes).  keep >= 0: only that
-// rank's records survive (the arrays then hold counts[keep] records).
-static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts, DBuf<u64> *b2 = nullptr,
-                             int keep = -1)
+// stable partition of (a[, c][, b2]) by destination rank, all arrays in one scatter pass (radix_partition); counts[r] =
+// records for rank r.  mode 0: the top bits of a as they are (hash ranges), 1: hashed (seed codes).
+static int partition_by_dest(cora_hip_job *job, DBuf<u64> &a, DBuf<u32> *c, u64 n, int mode, int world, uint64_t *counts, DBuf<u64> *b2 = nullptr)
 {
     hipStream_t s = job->stream;
     for (int r = 0; r < world; r++) counts[r] = 0;
     if (world == 1 || n == 0) { counts[0] = (world == 1) ? n : 0; return 0; }
-    const int dmode = mode == 0 ? 1 : 2;
-    SortArrays keys, out;
-    keys.a = a.p; keys.b = b2 ? b2->p : nullptr; keys.c = c ? c->p : nullptr;
-    if (radix_partition_count(s, keys, n, dmode, (u32)world, job->sort_scratch, counts)) return fail(100, "partition failed");
-    const u64 n_out = keep < 0 ? n : counts[keep];
     DBuf<u64> ta, tb;
     DBuf<u32> tc;
-    RCQ(ta.alloc(n_out));
-    if (c) RCQ(tc.alloc(n_out));
-    if (b2) RCQ(tb.alloc(n_out));
-    out.a = ta.p; out.b = b2 ? tb.p : nullptr; out.c = c ? tc.p : nullptr;
-    if (radix_partition_move(s, keys, out, n, dmode, (u32)world, keep, n_out, job->sort_scratch, &job->sort_timing)) return fail(100, "partition failed");
+    RCQ(ta.alloc(n));
+    if (c) RCQ(tc.alloc(n));
+    if (b2) RCQ(tb.alloc(n));
+    SortArrays keys, tmp;
+    keys.a = a.p; keys.b = b2 ? b2->p : nullptr; keys.c = c ? c->p : nullptr;
+    tmp.a = ta.p; tmp.b = b2 ? tb.p : nullptr; tmp.c = c ? tc.p : nullptr;
+    if (radix_partition(s, keys, tmp, n, mode == 0 ? 1 : 2, (u32)world, job->sort_scratch, &job->sort_timing, counts)) return fail(100, "partition failed");
     HIPQ(hipGetLastError());
+    // one pass: the result sits in what were the spare arrays
     swap_buf(a, ta);
     if (c) swap_buf(*c, tc);
     if (b2) swap_buf(*b2, tb);
     return 0;
+}
+
+// filter mode: what the KMERS / SEED stage generated for ALL positions stays in the send arrays; the owner's sort reads it
+// from there and keeps its own records in its first pass (radix_sort's SortSource)
+static SortSource source_of(const ShardState &sh, int fmode, bool with_b, bool with_c)
+{
+    SortSource f;
+    f.src.a = sh.send_a.p; f.src.b = with_b ? sh.send_b.p : nullptr; f.src.c = with_c ? sh.send_c.p : nullptr;
+    f.n = sh.n_send; f.fmode = fmode; f.world = (u32)sh.world; f.me = (u32)sh.rank;
+    return f;
 }
 
 extern "C" int cora_hip_shard_begin(cora_hip_job *job, int rank, int world)
@@ -148,12 +155,9 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     if (!counts) counts = local_counts;
     switch (stage) {
     case ST_KMERS: {
-        if (sh.filter) {                // all positions; what the partition keeps is this rank's received set
+        if (sh.filter) {                // all positions; EXACT's sort keeps this rank's records
             RCQ(st_kmers(job, 0, (u32)((dp.G + 255) / 256), sh.send_a, sh.send_c, sh.n_send));
-            RCQ(partition_by_dest(job, sh.send_a, &sh.send_c, sh.n_send, 0, sh.world, counts, nullptr, sh.rank));
-            swap_buf(sh.recv_a, sh.send_a); swap_buf(sh.recv_c, sh.send_c);
-            sh.n_recv = counts[sh.rank]; sh.n_send = 0;
-            sh.send_a.release(); sh.send_c.release();
+            for (int r = 0; r < sh.world; r++) counts[r] = 0;
             return 0;
         }
         RCQ(st_kmers(job, sh.blk_lo, sh.blk_n, sh.send_a, sh.send_c, sh.n_send));
@@ -162,6 +166,18 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     }
     case ST_EXACT: {
         sh.x.release_all();
+        if (sh.filter) {
+            const SortSource from = source_of(sh, 1, false, true);
+            u64 kept = 0;
+            if (radix_sort_count_kept(s, from, 64 - exact_sort_bits(job), 64, job->sort_scratch, &kept)) return fail(100, "radix sort failed");
+            sh.x.N = kept;
+            RCQ(sh.x.rec.alloc(kept)); RCQ(sh.x.gp.alloc(kept));
+            job->stats.kmers = kept;
+            RCQ(st_exact_classes(job, sh.x, &from));
+            sh.send_a.release(); sh.send_c.release(); sh.n_send = 0;
+            job->stats.representatives = sh.x.NR; job->stats.exact_classes = sh.x.NNS;
+            return 0;
+        }
         sh.x.N = sh.n_recv;
         std::swap(sh.x.rec.p, sh.recv_a.p); std::swap(sh.x.rec.n, sh.recv_a.n); std::swap(sh.x.rec.pool, sh.recv_a.pool);
         std::swap(sh.x.gp.p, sh.recv_c.p); std::swap(sh.x.gp.n, sh.recv_c.n); std::swap(sh.x.gp.pool, sh.recv_c.pool);
@@ -208,17 +224,29 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
             launch_seed_codes(s, dp, job->pk.p, sh.reps.p, sh.n_reps, arg, sh.send_a.p);
         }
         HIPQ(hipStreamSynchronize(s));
-        RCQ(partition_by_dest(job, sh.send_a, nullptr, sh.n_send, 1, sh.world, counts, sh.seed_sketch ? &sh.send_b : nullptr,
-                              sh.filter ? sh.rank : -1));
-        if (sh.filter) {
-            swap_buf(sh.recv_a, sh.send_a);
-            if (sh.seed_sketch) swap_buf(sh.recv_b, sh.send_b); else sh.recv_b.release();
-            sh.n_recv = counts[sh.rank]; sh.n_send = 0;
-            sh.send_a.release(); sh.send_b.release();
+        if (sh.filter) {                // VERIFY's sort keeps this rank's records
+            for (int r = 0; r < sh.world; r++) counts[r] = 0;
+            return 0;
         }
+        RCQ(partition_by_dest(job, sh.send_a, nullptr, sh.n_send, 1, sh.world, counts, sh.seed_sketch ? &sh.send_b : nullptr));
         return 0;
     }
     case ST_VERIFY: {
+        if (sh.filter) {
+            const SortSource from = source_of(sh, 2, sh.seed_sketch, false);
+            const int lo = seed_sort_lo(sh.seed_sketch);
+            u64 kept = 0;
+            if (radix_sort_count_kept(s, from, lo, lo + 32, job->sort_scratch, &kept)) return fail(100, "radix sort failed");
+            if (kept) {
+                RCQ(sh.recv_a.alloc(kept));
+                if (sh.seed_sketch) RCQ(sh.recv_b.alloc(kept));
+                RCQ(st_seed_verify(job, sh.recv_a, kept, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, &from));
+            }
+            sh.recv_a.release(); sh.send_a.release(); sh.recv_b.release(); sh.send_b.release();
+            sh.n_send = sh.n_recv = 0;
+            job->stats.hom_pairs = sh.ps.n;
+            return 0;
+        }
         if (sh.seed_sketch && sh.n_recv && !sh.recv_b.p) return fail(19, "the seed records' sketches have not been delivered");
         if (sh.n_recv) RCQ(st_seed_verify(job, sh.recv_a, sh.n_recv, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr));
         sh.recv_a.release(); sh.send_a.release(); sh.recv_b.release(); sh.send_b.release();

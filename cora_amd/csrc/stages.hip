@@ -38,7 +38,9 @@ int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf
 // Sort the records, group equal canonical K-mers exactly, mark the non-representatives, list the classes with >= 2
 // entries and find the first singleton (HTS:2516-2578).  x.rec / x.gp hold x.N records in which equal K-mers
 // appear in increasing position.
-int st_exact_classes(cora_hip_job *job, ExactLocal &x)
+// from (multi-GPU flow on few GPUs): the sort's first pass reads ALL records of the reference from there and keeps the
+// x.N this rank owns (radix_sort_count_kept has run on the same bit range, exact_sort_bits); x.rec / x.gp are then only sized.
+int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
@@ -53,10 +55,10 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x)
     // (6-7 passes) instead of 20-byte full keys on 2K bits (13 passes); collisions are found and repaired below.
     // About N^2 / 2^(hb+1) pairs of different K-mers collide: a thousand at 64 M records, 2e6 at 3e9 -- repaired in 3 ms,
     // where a sixth pass over 3e9 records costs 20 (48 bits: CORA_HASH_BITS=48).
-    const int hb = job->hash_bits ? job->hash_bits : 40;
+    const int hb = exact_sort_bits(job);
     SortArrays keys, tmp;
     keys.a = x.rec.p; keys.c = x.gp.p; tmp.a = x.trec.p; tmp.c = x.tgp.p;
-    if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+    if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing, nullptr, from)) return fail(100, "radix sort failed");
     DevCounters h;
     ZERO_COUNTERS(job, n_mixed, 2);                              // n_mixed, fallback
     {
@@ -245,7 +247,8 @@ int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBu
 // One seed: sort the (code, position) records, compact the run members, verify, append the pair records
 // (HTS:2671-2800, 2138-2265).  codes holds n records in which equal codes appear in increasing position.
 // sk_b / sk_c: the records' sketches (k_seed_codes_all), sorted along with them; either or both may be null.
-int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u64 *sk_b, u32 *sk_c)
+// from: as in st_exact_classes (the bit range is seed_sort_lo / _hi); codes / sk_b are then only sized for the n kept records.
+int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u64 *sk_b, u32 *sk_c, const SortSource *from)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
@@ -259,8 +262,8 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     if (sk_b) { RCQ(skb_tmp.alloc(n)); ck.b = sk_b; ct.b = skb_tmp.p; }               // the sketches travel with their records
     if (sk_c) { RCQ(skc_tmp.alloc(n)); ck.c = sk_c; ct.c = skc_tmp.p; }
     // the records are a (code << 32 | position); with a b array the sort's logical key is a:b, i.e. a's bits sit 64 higher
-    const int key_lo = sk_b ? 96 : 32, key_hi = sk_b ? 128 : 64;
-    if (radix_sort(s, ck, ct, n, key_lo, key_hi, job->sort_scratch, &job->sort_timing, first_hist)) return fail(100, "radix sort failed");
+    const int key_lo = seed_sort_lo(sk_b != nullptr), key_hi = key_lo + 32;
+    if (radix_sort(s, ck, ct, n, key_lo, key_hi, job->sort_scratch, &job->sort_timing, first_hist, from)) return fail(100, "radix sort failed");
     const u64 ab = verify_blocks(n);                             // workgroups (tiles) of the candidate kernels
     u64 totals[2] = {0, 0};                                      // slots, comparisons
     DBuf<PairRec> slots;
