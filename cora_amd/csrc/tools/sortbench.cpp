@@ -82,6 +82,7 @@ int main(int argc, char **argv)
 {
     const u64 n = argc > 1 ? strtoull(argv[1], 0, 10) : 64000000ull;
     const int reps = argc > 2 ? atoi(argv[2]) : 5;
+    const bool only_sorts = argc > 3 && !strcmp(argv[3], "sorts");      // skip the ceilings and the rocPRIM yardstick
     u64 *a, *ta; u32 *c, *tc;
     CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&ta, n * 8)); CK(hipMalloc(&c, n * 4)); CK(hipMalloc(&tc, n * 4));
     hipStream_t s; CK(hipStreamCreate(&s));
@@ -89,7 +90,7 @@ int main(int argc, char **argv)
     SortScratch scr;
     float ms;
     // copy peak
-    for (int withc = 1; withc >= 0; withc--) {
+    for (int withc = 1; withc >= 0 && !only_sorts; withc--) {
         k_fill<<<4096, 256, 0, s>>>(a, c, n, 1);
         CK(hipEventRecord(e0, s));
         for (int r = 0; r < reps; r++) k_copy<<<8192, 256, 0, s>>>(a, withc ? c : nullptr, ta, tc, n);
@@ -97,13 +98,13 @@ int main(int argc, char **argv)
         const double bytes = 2.0 * n * (withc ? 12 : 8);
         printf("copy %2d B records: %.3f ms  %.0f GB/s\n", withc ? 12 : 8, ms / reps, bytes * reps / ms / 1e6);
     }
-    for (int blocks = 2048; blocks <= 32768; blocks *= 4) {
+    for (int blocks = 2048; blocks <= 32768 && !only_sorts; blocks *= 4) {
         CK(hipEventRecord(e0, s));
         for (int r = 0; r < reps; r++) k_read<<<blocks, 256, 0, s>>>((const ulonglong2 *)a, n / 2, ta);
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         printf("read-only 8 B records, %5d blocks: %.3f ms  %.0f GB/s\n", blocks, ms / reps, 8.0 * n * reps / ms / 1e6);
     }
-    {
+    if (!only_sorts) {
         u32 *th; CK(hipMalloc(&th, (n / 4096 + 2) * 1024));
         const unsigned tiles = (unsigned)(n / 4096);
         for (int mode = 0; mode < 4; mode++) {
@@ -148,7 +149,7 @@ int main(int argc, char **argv)
                (unsigned long long)n, tot / reps, launches / reps, sc / launches, scb / sc / 1e6, scb / tot / 1e6);
     }
     // rocPRIM yardstick
-    {
+    if (!only_sorts) {
         size_t tb = 0;
         CK(rocprim::radix_sort_pairs(nullptr, tb, a, ta, c, tc, n, 16, 64, s));
         void *tmp; CK(hipMalloc(&tmp, tb));
