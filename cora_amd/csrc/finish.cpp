@@ -5,6 +5,8 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
@@ -350,12 +352,22 @@ bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> 
     ByteBuf hb;
     std::vector<size_t> marks;
     FinishStats hst;
+    const bool trace = getenv("CORA_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cora]   assemble: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (hnodes.size() && !serialize_inexact(g, host_items, packed, hb, hst, n_threads, &marks)) return false;
+    mark("host lists");
     st.inexact_nodes = device_nodes + hst.inexact_nodes;
     st.dirty_nodes = hst.dirty_nodes; st.big_nodes = hst.big_nodes;
     const size_t total = stream.size() + hb.size();
     if (!out.reserve_uninit(total + 16)) return false;
     out.n = total;
+    mark("table buffer");
     // the stream arrives in steps; a piece is copied once the stream bytes it reads are there (need), host pieces at once
     std::vector<size_t> upto;
     if (arrival) upto = arrival->upto;
@@ -385,6 +397,7 @@ bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> 
     if (stream.size() > s_at) add_stream(s_at, d_at, stream.size() - s_at);
     int T = n_threads < 1 ? 1 : n_threads;
     if (total < (4u << 20)) T = 1;
+    mark("piece list");
     size_t lo = 0;
     for (size_t c = 0; c < upto.size(); c++) {
         if (arrival && arrival->wait && !arrival->wait(c)) return false;
@@ -397,6 +410,7 @@ bool assemble_inexact(const HostGenome &g, View<uint8_t> stream, View<HostNode> 
         work(0);
         for (auto &x : th) x.join();
         lo = hi;
+        mark("stream part moved");
     }
     return true;
 }

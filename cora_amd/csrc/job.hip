@@ -66,6 +66,7 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
 extern "C" void cora_hip_job_destroy(cora_hip_job *job)
 {
     if (!job) return;
+    join_warm(job);
     multi_state_free(job);
     (void)hipSetDevice(job->device);
     shard_state_free(job);
@@ -181,13 +182,33 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     // ---- stage 1: pack, hashed K-mer records (HTS:2499-2565) ----
     if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }   // (a run that failed half-way)
     RCQ(st_pack(job));
-    {
+    join_warm(job);
+    const size_t packed_words = dp.n_words + 4;
+    if (job->h_packed.cap < packed_words && !job->h_stream.cap && !job->inexact_bytes.p && job->genome_bases >= (256ull << 20)) {
+        // The first build of a job on a large reference pays for its host buffers: pinning the landing areas of the packed
+        // reference and of the byte stream, the first CPU touch of every pinned page (the copy threads of assemble_inexact
+        // moved 14 GB/s out of a fresh h_stream against 67 GB/s later) and the page faults of a fresh <Inexact> buffer --
+        // 100 of the 130 ms such a build took longer than the following ones.  None of them is needed before the lists are
+        // finished 0.6 s from now, so a helper thread prepares them beside the kernels; the byte stream's size is a guess
+        // (0.4 B per base; 0.27 on the GRCh38-like workload: a wrong guess costs memory or, too small, what it cost before).
+        // The packed reference then travels when st_items_finish asks for it (15 ms) instead of right now.
+        const size_t est = (size_t)(job->genome_bases / 5 * 2);
+        const int dev = job->device;
+        job->warm = std::thread([job, est, dev, packed_words] {
+            if (hipSetDevice(dev) != hipSuccess) return;
+            auto touch = [](const volatile uint8_t *p, size_t n) { uint8_t x = 0; for (size_t o = 0; o < n; o += 4096) x ^= p[o]; return x; };
+            if (!job->h_packed.reserve(packed_words)) (void)touch((const uint8_t *)job->h_packed.p, packed_words * sizeof(u64));
+            if (!job->h_stream.reserve(est)) (void)touch(job->h_stream.p, est);
+            if (job->inexact_bytes.reserve_uninit(est))
+                for (size_t o = 0; o < est; o += 4096) job->inexact_bytes.p[o] = 0;
+        });
+    } else {
         // the packed reference starts its way to the host now (0.25 B per base over PCIe beside 0.8 s of kernels): lists
         // with tied targets are finished there and read their K-mers from it (st_items_finish)
-        RCQ(job->h_packed.reserve(dp.n_words + 4));
+        RCQ(job->h_packed.reserve(packed_words));
         HIPQ(hipEventRecord(job->ev_copy[4], s));
         HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[4], 0));
-        HIPQ(hipMemcpyAsync(job->h_packed.p, job->pk.p, (dp.n_words + 4) * sizeof(u64), hipMemcpyDeviceToHost, job->copy_stream));
+        HIPQ(hipMemcpyAsync(job->h_packed.p, job->pk.p, packed_words * sizeof(u64), hipMemcpyDeviceToHost, job->copy_stream));
         HIPQ(hipEventRecord(job->ev_copy[9], job->copy_stream));
         job->packed_in_flight = true;
     }

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace cora;
@@ -162,7 +163,7 @@ struct cora_hip_job {
     DevPool pool;
     HBuf<u64> h_key, h_packed;
     HBuf<u32> h_meta, h_node_start;
-    HBuf<u8> h_stream;
+    HBuf<u8> h_stream, h_exact;   // landing areas of the <Inexact> byte stream and of the <Exact> bytes
     HBuf<HostNode> h_hnodes;
     HBuf<int16_t> h_blen;
     int host_threads = 8;
@@ -175,8 +176,13 @@ struct cora_hip_job {
     int sketch_mode = -1;         // -1 = by size (job.hip: SKETCH_MIN_REPS); CORA_SKETCH=0/1 overrides
     int hash_bits = 0;            // 0 = by size; CORA_HASH_BITS overrides (tests force collisions with small values)
     ByteBuf exact_bytes, inexact_bytes;
+    // First build of a job on a large reference: a helper thread pins h_stream and faults in the pages of inexact_bytes
+    // beside the kernels (job.hip); whoever touches either buffer calls join_warm first.
+    std::thread warm;
     cora_hip_stats stats;
 };
+
+inline void join_warm(cora_hip_job *job) { if (job->warm.joinable()) job->warm.join(); }
 
 inline int read_counters(cora_hip_job *job, DevCounters &h)
 {

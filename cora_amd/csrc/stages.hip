@@ -207,7 +207,7 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
         RCQ(stream.alloc(total));
         launch_exact_write(s, dp, cw, ce_s.p, eoff_s.p, p.ent.p, p.edir.p, mp.p, (u32)n, csize.p, coff.p, stream.p, job->ctr.p);
         View<u8> bytes;
-        RCQ(d2h(job, job->h_stream, bytes, (const u8 *)stream.p, total));
+        RCQ(d2h(job, job->h_exact, bytes, (const u8 *)stream.p, total));      // (its own landing area: h_stream may still be in preparation, job.hip)
         RCQ(read_counters(job, h));
         HIPQ(hipGetLastError());
         const auto h0 = std::chrono::steady_clock::now();
@@ -319,6 +319,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
 // F2 bytes (HTS:1353-1432).  ik/im hold M items in any order.
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms)
 {
+    join_warm(job);                                  // (the host buffers this stage fills may still be in preparation)
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
     InexactDeviceResult ir;                 // the items of the lists the host finishes
@@ -437,7 +438,13 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
             arrival.upto.push_back((size_t)piece_off[c + 1]);
         }
         HIPQ(hipGetLastError());
-        arrival.wait = [job](size_t c) { return hipEventSynchronize(job->ev_copy[5 + c]) == hipSuccess; };
+        arrival.wait = [job](size_t c) {
+            static const bool trace = getenv("CORA_TRACE") != nullptr;
+            const auto w0 = std::chrono::steady_clock::now();
+            const bool ok = hipEventSynchronize(job->ev_copy[5 + c]) == hipSuccess;
+            if (trace) fprintf(stderr, "[cora]   stream piece %zu: waited %.3f ms for it\n", c, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+            return ok;
+        };
         have_arrival = true;
         if (packed_host.n && job->packed_in_flight) HIPQ(hipEventSynchronize(job->ev_copy[9]));      // (sent 0.7 s ago)
         trace_mark(job, "items: copies queued", 7);
