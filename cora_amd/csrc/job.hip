@@ -454,6 +454,48 @@ extern "C" int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint3
     return 0;
 }
 
+// The sort whose first pass keeps one rank's records (radix_sort_count_kept + SortSource: the multi-GPU flow on few GPUs),
+// on host buffers: all n records in, the kept ones out, sorted.
+extern "C" int cora_hip_test_sort_kept_host(const uint64_t *key_hi, const uint64_t *key_lo, const uint32_t *val, uint64_t n, int bit_lo, int bit_hi,
+                                            int owner_mode, uint32_t world, uint32_t me, uint64_t *out_hi, uint64_t *out_lo, uint32_t *out_val,
+                                            uint64_t cap, uint64_t *n_kept)
+{
+    if (g_device < 0) return fail(102, "cora_hip_init has not succeeded");
+    if (!key_hi || !out_hi || !n_kept || (key_lo && !out_lo) || (val && !out_val)) return fail(19, "null argument");
+    hipStream_t s = nullptr;
+    DBuf<u64> a, b, ka, kb, ta, tb;
+    DBuf<u32> c, kc, tc;
+    RCQ(a.alloc(n));
+    HIPQ(hipMemcpy(a.p, key_hi, n * sizeof(u64), hipMemcpyHostToDevice));
+    if (key_lo) { RCQ(b.alloc(n)); HIPQ(hipMemcpy(b.p, key_lo, n * sizeof(u64), hipMemcpyHostToDevice)); }
+    if (val) { RCQ(c.alloc(n)); HIPQ(hipMemcpy(c.p, val, n * sizeof(u32), hipMemcpyHostToDevice)); }
+    SortSource from;
+    from.src.a = a.p; from.src.b = key_lo ? b.p : nullptr; from.src.c = val ? c.p : nullptr;
+    from.n = n; from.fmode = owner_mode; from.world = world; from.me = me;
+    SortScratch scratch;
+    u64 kept = 0;
+    int rc = radix_sort_count_kept(s, from, bit_lo, bit_hi, scratch, &kept);
+    if (rc) { scratch.release(); return fail(19, "radix_sort_count_kept refused the arguments (%d)", rc); }
+    *n_kept = kept;
+    if (kept > cap) { scratch.release(); return fail(19, "%llu records kept, room for %llu", (unsigned long long)kept, (unsigned long long)cap); }
+    RCQ(ka.alloc(kept)); RCQ(ta.alloc(kept));
+    if (key_lo) { RCQ(kb.alloc(kept)); RCQ(tb.alloc(kept)); }
+    if (val) { RCQ(kc.alloc(kept)); RCQ(tc.alloc(kept)); }
+    SortArrays keys, tmp;
+    keys.a = ka.p; keys.b = key_lo ? kb.p : nullptr; keys.c = val ? kc.p : nullptr;
+    tmp.a = ta.p; tmp.b = key_lo ? tb.p : nullptr; tmp.c = val ? tc.p : nullptr;
+    rc = radix_sort(s, keys, tmp, kept, bit_lo, bit_hi, scratch, nullptr, nullptr, &from);
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    scratch.release();
+    if (rc) return fail(100, "radix sort failed (%d)", rc);
+    if (kept) {
+        HIPQ(hipMemcpy(out_hi, keys.a, kept * sizeof(u64), hipMemcpyDeviceToHost));
+        if (key_lo) HIPQ(hipMemcpy(out_lo, keys.b, kept * sizeof(u64), hipMemcpyDeviceToHost));
+        if (val) HIPQ(hipMemcpy(out_val, keys.c, kept * sizeof(u32), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
 extern "C" int cora_hip_test_pack(cora_hip_job *job, uint64_t *packed, uint32_t *bad, uint64_t *contig_start, uint64_t *padded_len)
 {
     if (!job || !job->have_ref) return fail(51, "no reference set");

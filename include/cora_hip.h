@@ -388,6 +388,14 @@ uint64_t cora_hip_radix_sort_noalloc_max(void);
 
 /* Host-buffer convenience wrappers for tests: copy in, run the kernels, copy out. */
 int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val, uint64_t n, int bit_lo, int bit_hi);
+/* The same sort with the owner filter of the multi-GPU flow on few GPUs (cora_hip_shard_filter): of the n records only those
+ * whose owner is `me` of `world` ranks are kept -- owner = top 32 bits of key_hi (owner_mode 1: as they are, hash ranges;
+ * 2: multiplied by 0x9E3779B1 mod 2^32, seed codes) * world >> 32 -- in the first pass of the sort, which reads all
+ * records and writes the kept ones.  out_* (room for cap records) receive them sorted; *n_kept their number.  With key_lo the
+ * bit range must lie in key_hi (bit_lo >= 64).  No counterpart in the reference. */
+int cora_hip_test_sort_kept_host(const uint64_t *key_hi, const uint64_t *key_lo, const uint32_t *val, uint64_t n, int bit_lo, int bit_hi,
+                                 int owner_mode, uint32_t world, uint32_t me, uint64_t *out_hi, uint64_t *out_lo, uint32_t *out_val,
+                                 uint64_t cap, uint64_t *n_kept);
 /* The device replica of libstdc++'s std::sort with the reference's comparator sort_by_decreasing_blockLen (HTS:1110-1113,
  * used at HTS:1368): sorts n u32 elements (block length + 1) << 25 | index, comparing the top 7 bits only, with ONE GPU
  * thread, as the table writer does for every list above 16 items.  forced_depth >= 0 replaces introsort's depth limit

@@ -56,6 +56,41 @@ def test_radix_sort_partial_bits():
     assert np.array_equal(val, order.astype(np.uint32))
 
 
+@pytest.mark.parametrize("n", [0, 1, 5000, 8192, 8193, 300_001])
+@pytest.mark.parametrize("shape,owner_mode,world", [("key", 1, 2), ("key", 2, 3), ("key+payload", 1, 4), ("key+payload", 1, 7), ("two words", 2, 2),
+                                                    ("two words", 2, 5)])
+def test_radix_sort_that_keeps_one_ranks_records(n, shape, owner_mode, world):
+    """The first pass of a rank's sort in the few-GPU flow reads ALL records and keeps the ones the rank owns
+    (radix_sort_count_kept, rs_scatter<FILTER>): for every rank, the result is numpy's stable sort of exactly those records;
+    the three record shapes are the seed records without sketches, the K-mer records and the seed records with sketches."""
+    hip.init(0)
+    rs = np.random.RandomState(n % 1000 + world)
+    hi = (rs.randint(0, 2 ** 32, size=n).astype(np.uint64) << np.uint64(32)) | rs.randint(0, 2 ** 32, size=n).astype(np.uint64)
+    if n > 10:
+        hi[n // 3:n // 3 + n // 5] = hi[n // 3]                  # a long run of one key: one owner, ties in input order
+    lo = rs.randint(0, 2 ** 62, size=n).astype(np.uint64) if shape == "two words" else None
+    val = np.arange(n, dtype=np.uint32) if shape == "key+payload" else None
+    top = (hi >> np.uint64(32)).astype(np.uint64)
+    if owner_mode == 2:
+        top = (top * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    owner = (top * np.uint64(world)) >> np.uint64(32)
+    bit_lo, bit_hi = (96, 128) if lo is not None else ((24, 64) if val is not None else (32, 64))
+    sh = np.uint64(bit_lo - 64 if lo is not None else bit_lo)
+    total = 0
+    for me in range(world):
+        idx = np.nonzero(owner == np.uint64(me))[0]
+        order = idx[np.argsort(hi[idx] >> sh, kind="stable")]
+        got_hi, got_lo, got_val = hip.sort_kept_host(hi, lo, val, bit_lo, bit_hi, owner_mode, world, me)
+        assert len(got_hi) == len(idx)
+        assert np.array_equal(got_hi, hi[order])
+        if lo is not None:
+            assert np.array_equal(got_lo, lo[order])
+        if val is not None:
+            assert np.array_equal(got_val, order.astype(np.uint32))
+        total += len(got_hi)
+    assert total == n
+
+
 # ------------------------------------------------------------------ pack / keys vs numpy
 def _np_pack(contigs, G, starts):
     code = np.full(G, 0, dtype=np.uint8)
