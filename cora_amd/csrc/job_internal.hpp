@@ -238,11 +238,11 @@ struct ExactLocal {                  // device results of class detection over o
     DBuf<u32> gp, tgp;
     const u64 *rec_s = nullptr;
     const u32 *gp_s = nullptr;
-    DBuf<u32> class_start;           // [NR+1]
+    DBuf<u32> cls_m;                 // [NNS] records of each class with >= 2 entries
     DBuf<u32> nonrep;                // [n_words] later members of this rank's classes (every valid window not in here is a representative)
-    DBuf<u64> cls;                   // [NNS] rep<<32 | class index, classes with >= 2 entries
+    DBuf<u64> cls;                   // [NNS] rep<<32 | index of the first record, classes with >= 2 entries
     u64 N = 0, NR = 0, NNS = 0;
-    void release_all() { rec.release(); trec.release(); gp.release(); tgp.release(); class_start.release(); nonrep.release(); cls.release(); rec_s = nullptr; gp_s = nullptr; }
+    void release_all() { rec.release(); trec.release(); gp.release(); tgp.release(); cls_m.release(); nonrep.release(); cls.release(); rec_s = nullptr; gp_s = nullptr; }
 };
 struct ExactParts {                  // entry lists of classes, ent laid out in the order of cls
     DBuf<u64> cls;

@@ -569,26 +569,44 @@ __device__ __forceinline__ bool key_is_palindrome(int K, u64 hi, u64 lo)
     return rhi == hi && rlo == lo;
 }
 
-// One thread per class (class_start from the scan of the head flags).  Per block of 256 classes: the
-// number of classes with >= 2 entries (>= 2 occurrences, or a palindrome: Q2) and the smallest
-// (group, position) of a singleton class.  The latter locates the first singleton in the reference's
-// class-id order: classes created before it escape the direction flip (Q3, HTS:421-433).  Per-block
-// partials instead of global counters: same-address atomics cost about 12 ns each chip-wide.
-__global__ __launch_bounds__(256) void k_class_count(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
-                                                     const u32 *__restrict__ class_start, u32 n_cls,
-                                                     u32 *__restrict__ blk_nons, unsigned long long *__restrict__ blk_min,
-                                                     u64 *__restrict__ nons_mask)
+// One thread per sorted record; head_mask bit i = record i opens a class.  Everything is read in record order (coalesced):
+// a class is a singleton exactly when the next record opens a class too, so no class-start array is needed.
+// Per block of 256 records: the number of classes with >= 2 entries (>= 2 occurrences, or a palindrome: Q2) that open in
+// it and the smallest (group, position) of a singleton class.  The latter locates the first singleton in the reference's
+// class-id order: classes created before it escape the direction flip (Q3, HTS:421-433).  Per-block partials instead of
+// global counters: same-address atomics cost about 12 ns each chip-wide.  nons_mask: bit i = record i opens a class with
+// >= 2 entries (one ballot word per wave).  Later members of classes (records that open nothing) are marked in nonrep:
+// representatives = first (lowest) position of every class (HTS:2573-2578) = every valid window that is not marked; later
+// members are few (the repeated K-mers), so they are what gets marked, by atomics, in a zeroed bitmap.
+// (Round 2 first ran this per CLASS over an array of class starts: start -> record -> position was a chain of dependent
+//  gathers, 14.9 ms at 2.6e9 classes, plus 5.4 ms for marking the later members and 1.9 ms for listing the starts.)
+__global__ __launch_bounds__(256) void k_class_scan(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
+                                                    const u64 *__restrict__ head_mask, u64 n, u32 *__restrict__ blk_nons,
+                                                    unsigned long long *__restrict__ blk_min, u64 *__restrict__ nons_mask,
+                                                    u32 *__restrict__ nonrep)
 {
     __shared__ u32 s_nons[4];
     __shared__ unsigned long long s_min[4];
-    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     bool nons = false;
     unsigned long long key = ~0ull;
-    if (c < n_cls) {
-        const u32 st = class_start[c], m = class_start[c + 1] - st;
-        const u32 fl = (u32)rec[st] & 0xFFu;
-        if (m == 1 && !(fl & 2u)) key = ((unsigned long long)(fl >> 2) << 32) | gpos[st];
-        else nons = true;
+    const u64 hw = (i - lane < n) ? head_mask[i >> 6] : 0ull;              // this wave's 64 head bits
+    // does record i + 1 open a class?  (lane 63 asks the next word; past the end counts as "yes")
+    u64 nw = 1ull;
+    if (lane == 63 && i + 1 < n) nw = head_mask[(i >> 6) + 1];
+    if (i < n) {
+        const bool head = (hw >> lane) & 1ull;
+        const u64 r = rec[i];
+        const u32 g = gpos[i];
+        if (head) {
+            const bool next_opens = (i + 1 >= n) || (lane == 63 ? (nw & 1ull) : ((hw >> (lane + 1)) & 1ull));
+            const u32 fl = (u32)r & 0xFFu;
+            if (next_opens && !(fl & 2u)) key = ((unsigned long long)(fl >> 2) << 32) | g;
+            else nons = true;
+        } else {
+            atomicOr(&nonrep[g >> 5], 1u << (31 - (g & 31)));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -596,8 +614,7 @@ __global__ __launch_bounds__(256) void k_class_count(const u64 *__restrict__ rec
         key = other < key ? other : key;
     }
     const u64 bn = __ballot(nons);
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; nons_mask[c >> 6] = bn; }   // kept for k_class_emit
+    if (lane == 0) { s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; nons_mask[i >> 6] = bn; }   // kept for k_class_emit
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_nons[blockIdx.x] = s_nons[0] + s_nons[1] + s_nons[2] + s_nons[3];
@@ -625,19 +642,6 @@ __global__ __launch_bounds__(256) void k_min_u64(const unsigned long long *__res
     }
 }
 
-// Representatives = first (lowest) position of every class (HTS:2573-2578) = every valid window that is not a
-// later member of a class.  Later members are few (the repeated K-mers), so they are what gets marked, by
-// atomics, in a zeroed bitmap; k_rep_mask then turns "valid and not marked" into the representative bitmap.
-// (Marking the representatives themselves cost one scattered atomic per distinct K-mer: 2.4 ms per 64 Mbp.)
-__global__ __launch_bounds__(256) void k_nonrep_mark(const u64 *__restrict__ head_mask, const u32 *__restrict__ gpos, u64 n,
-                                                     u32 *__restrict__ nonrep)
-{
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || ((head_mask[i >> 6] >> (i & 63)) & 1ull)) return;
-    const u32 g = gpos[i];
-    atomicOr(&nonrep[g >> 5], 1u << (31 - (g & 31)));
-}
-
 // the same from the stored window-validity bitmap (single-GPU run: k_kmer_count covered every position)
 __global__ __launch_bounds__(256) void k_rep_mask_words(const u32 *__restrict__ valid, const u32 *nonrep, u32 *rep, u64 n_words)
 {
@@ -653,20 +657,57 @@ __global__ __launch_bounds__(256) void k_rep_mask(DevParams p, const u32 *__rest
     if (w < p.n_words) rep[w] = window_bits(p, bad, w) & ~nonrep[w];
 }
 
-// Lists the classes with >= 2 entries as rep<<32 | class index, at offsets from the scan of blk_nons.
-__global__ __launch_bounds__(256) void k_class_emit(const u32 *__restrict__ gpos, const u32 *__restrict__ class_start, u32 n_cls,
-                                                    const u64 *__restrict__ nons_mask, u64 *__restrict__ cls,
+// Lists the classes with >= 2 entries as rep << 32 | index of their first record, and their sizes (records up to the next
+// class head), at offsets from the scan of blk_nons.  Same grid as k_class_scan.  The next head is in this record's mask
+// word or the one after it for all but the long classes; those (Mbp of tandem repeats make classes of 10^6 records, 16 000
+// empty mask words) are finished by the whole wave, 64 words per step.
+__global__ __launch_bounds__(256) void k_class_emit(const u32 *__restrict__ gpos, const u64 *__restrict__ head_mask, u64 n,
+                                                    const u64 *__restrict__ nons_mask, u64 *__restrict__ cls, u32 *__restrict__ cls_m,
                                                     const u64 *__restrict__ nons_off)
 {
-    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u64 w0 = (u64)blockIdx.x * 4;
-    const u64 bn = nons_mask[w0 + wv];                        // written for every wave of k_class_count's grid (same geometry)
-    if (c >= n_cls || !((bn >> lane) & 1ull)) return;
+    const u64 n_words = (n + 63) >> 6;
+    const u64 bn = (w0 + wv < n_words) ? nons_mask[w0 + wv] : 0ull;   // written for every wave of k_class_scan's grid (same geometry)
+    if (!bn) return;                                                   // (wave-uniform)
+    const bool mine = (bn >> lane) & 1ull;
+    u64 next = n;                                                      // index of the next class head
+    bool found = !mine;
+    if (mine) {
+        const u64 w = i >> 6;
+        const u64 rest = lane == 63 ? 0ull : (head_mask[w] >> (lane + 1));
+        if (rest) { next = i + 1 + (u64)(__ffsll((long long)rest) - 1); found = true; }
+        else if (w + 1 < n_words) {
+            const u64 b = head_mask[w + 1];
+            if (b) { next = (w + 1) * 64 + (u64)(__ffsll((long long)b) - 1); found = true; }
+        } else found = true;                                           // the last class: it ends with the records
+    }
+    u64 todo = __ballot(!found);
+    while (todo) {                                                     // long classes, one at a time, 64 mask words per step
+        const int src = __ffsll((long long)todo) - 1;
+        const u64 from = (__shfl(i, src, 64) >> 6) + 2;
+        u64 res = n;
+        for (u64 base = from; base < n_words; base += 64) {
+            const u64 w = base + lane;
+            const u64 b = w < n_words ? head_mask[w] : 0ull;
+            const u64 any = __ballot(b != 0);
+            if (any) {
+                const int l = __ffsll((long long)any) - 1;
+                const u64 bw = __shfl(b, l, 64);
+                res = (base + l) * 64 + (u64)(__ffsll((long long)bw) - 1);
+                break;
+            }
+        }
+        if (lane == src) next = res;
+        todo &= todo - 1;
+    }
+    if (!mine) return;
     u32 pre = 0;
     for (int w = 0; w < wv; w++) pre += (u32)__popcll(nons_mask[w0 + w]);
     const u64 at = nons_off[blockIdx.x] + pre + (u32)__popcll(bn & ((1ull << lane) - 1ull));
-    cls[at] = ((u64)gpos[class_start[c]] << 32) | (u64)c;
+    cls[at] = ((u64)gpos[i] << 32) | (u64)i;
+    cls_m[at] = (u32)(next - i);
 }
 
 // ------------------------------------------------------------------ record mask -> positions of the set bits
@@ -748,16 +789,15 @@ __device__ __forceinline__ bool note_huge(DevCounters::Huge *h, u32 id)
     return true;
 }
 
-// cls[k] = rep<<32 | class index, sorted by rep.  flags: bit0 palindrome, bit1 flip, bit2 rep strand, bit3 leading.
-__global__ __launch_bounds__(256) void k_class_info(const u64 *__restrict__ rec, const u32 *__restrict__ class_start,
+// cls[k] = rep<<32 | index of the class's first record, cls_m[k] = its records.  flags: bit0 palindrome, bit1 flip, bit2 rep strand, bit3 leading.
+__global__ __launch_bounds__(256) void k_class_info(const u64 *__restrict__ rec, const u32 *__restrict__ cls_m,
                                                     const u64 *__restrict__ cls, u32 n_cls, const DevCounters *__restrict__ ctr,
                                                     u32 *__restrict__ cls_flags, u32 *__restrict__ cls_entries)
 {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n_cls) return;
     const u64 rep = cls[k] >> 32;
-    const u32 c = (u32)cls[k];
-    const u32 st = class_start[c], m = class_start[c + 1] - st;
+    const u32 st = (u32)cls[k], m = cls_m[k];
     const u32 fl = (u32)rec[st] & 0xFFu;                        // flags of the representative's window
     const bool pal = fl & 2u, strand = fl & 1u;
     const unsigned long long ord = ((unsigned long long)(fl >> 2) << 32) | rep;
@@ -771,7 +811,7 @@ __global__ __launch_bounds__(256) void k_class_info(const u64 *__restrict__ rec,
 // dir = strandSwitched (HTS:2552-2565), flipped when the representative's is 1 (HTS:424-432);
 // a palindromic K-mer contributes (0,pos),(1,pos) (Q2, HTS:2597-2616).
 __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
-                                                       const u32 *__restrict__ class_start, const u64 *__restrict__ cls, u32 n_cls,
+                                                       const u32 *__restrict__ cls_m, const u64 *__restrict__ cls, u32 n_cls,
                                                        const u32 *__restrict__ cls_flags, const u64 *__restrict__ ent_off,
                                                        u32 *__restrict__ ent, u8 *__restrict__ ent_dir, DevCounters *ctr)
 {
@@ -781,8 +821,7 @@ __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ r
     __syncthreads();
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k < n_cls) {
-        const u32 c = (u32)cls[k];
-        const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[k];
+        const u32 st = (u32)cls[k], m = cls_m[k], fl = cls_flags[k];
         if (m > HUGE_MIN && note_huge(&ctr->huge_entries, k)) {
             // left to k_class_entries_huge
         } else if (m > COOP_MIN) {
@@ -802,8 +841,8 @@ __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ r
     __syncthreads();
     const u32 nbig = s_nbig;
     for (u32 b = 0; b < nbig; b++) {
-        const u32 kb = s_big[b], c = (u32)cls[kb];
-        const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[kb];
+        const u32 kb = s_big[b];
+        const u32 st = (u32)cls[kb], m = cls_m[kb], fl = cls_flags[kb];
         const u64 o = ent_off[kb];
         for (u32 j = threadIdx.x; j < m; j += 256) {
             const u32 g = gpos[st + j];
@@ -817,14 +856,14 @@ __global__ __launch_bounds__(256) void k_class_entries(const u64 *__restrict__ r
 }
 
 __global__ __launch_bounds__(256) void k_class_entries_huge(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
-                                                            const u32 *__restrict__ class_start, const u64 *__restrict__ cls,
+                                                            const u32 *__restrict__ cls_m, const u64 *__restrict__ cls,
                                                             const u32 *__restrict__ cls_flags, const u64 *__restrict__ ent_off,
                                                             u32 *__restrict__ ent, u8 *__restrict__ ent_dir, const DevCounters *ctr)
 {
     const u32 nh = ctr->huge_entries.n < 31u ? ctr->huge_entries.n : 31u;
     for (u32 h = 0; h < nh; h++) {
-        const u32 kb = ctr->huge_entries.id[h], c = (u32)cls[kb];
-        const u32 st = class_start[c], m = class_start[c + 1] - st, fl = cls_flags[kb];
+        const u32 kb = ctr->huge_entries.id[h];
+        const u32 st = (u32)cls[kb], m = cls_m[kb], fl = cls_flags[kb];
         const u64 o = ent_off[kb];
         for (u32 j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
             const u32 g = gpos[st + j];
@@ -2077,22 +2116,18 @@ void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, co
 {
     if (n) hipLaunchKernelGGL(k_heads_from_keys, grid_for(n), dim3(256), 0, s, p, pk, hi, lo, gpos, n, head_mask, rec);
 }
-void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
-                        unsigned long long *blk_min, u64 *nons_mask, DevCounters *ctr)
+void launch_class_scan(hipStream_t s, const u64 *rec, const u32 *gpos, const u64 *head_mask, u64 n, u32 *blk_nons,
+                       unsigned long long *blk_min, u64 *nons_mask, u32 *nonrep, DevCounters *ctr)
 {
-    if (!n_cls) return;
-    const dim3 g = grid_for(n_cls);
-    hipLaunchKernelGGL(k_class_count, g, dim3(256), 0, s, rec, gpos, class_start, n_cls, blk_nons, blk_min, nons_mask);
+    if (!n) return;
+    const dim3 g = grid_for(n);
+    hipLaunchKernelGGL(k_class_scan, g, dim3(256), 0, s, rec, gpos, head_mask, n, blk_nons, blk_min, nons_mask, nonrep);
     hipLaunchKernelGGL(k_min_u64, dim3(g.x < 64 ? g.x : 64), dim3(256), 0, s, blk_min, (u64)g.x, &ctr->first_singleton_key);
 }
-void launch_class_emit(hipStream_t s, const u32 *gpos, const u32 *class_start, u32 n_cls, const u64 *nons_mask, u64 *cls,
+void launch_class_emit(hipStream_t s, const u32 *gpos, const u64 *head_mask, u64 n, const u64 *nons_mask, u64 *cls, u32 *cls_m,
                        const u64 *nons_off)
 {
-    if (n_cls) hipLaunchKernelGGL(k_class_emit, grid_for(n_cls), dim3(256), 0, s, gpos, class_start, n_cls, nons_mask, cls, nons_off);
-}
-void launch_nonrep_mark(hipStream_t s, const u64 *head_mask, const u32 *gpos, u64 n, u32 *nonrep)
-{
-    if (n) hipLaunchKernelGGL(k_nonrep_mark, grid_for(n), dim3(256), 0, s, head_mask, gpos, n, nonrep);
+    if (n) hipLaunchKernelGGL(k_class_emit, grid_for(n), dim3(256), 0, s, gpos, head_mask, n, nons_mask, cls, cls_m, nons_off);
 }
 void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words)
 {
@@ -2118,18 +2153,18 @@ void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *
 {
     hipLaunchKernelGGL(k_bitmap_emit, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_off, out, base);
 }
-void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,
+void launch_class_info(hipStream_t s, const u64 *rec, const u32 *cls_m, const u64 *cls, u32 n_cls, const DevCounters *ctr,
                        u32 *cls_flags, u32 *cls_entries)
 {
-    if (n_cls) hipLaunchKernelGGL(k_class_info, grid_for(n_cls), dim3(256), 0, s, rec, class_start, cls, n_cls, ctr, cls_flags, cls_entries);
+    if (n_cls) hipLaunchKernelGGL(k_class_info, grid_for(n_cls), dim3(256), 0, s, rec, cls_m, cls, n_cls, ctr, cls_flags, cls_entries);
 }
-void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, const u64 *cls, u32 n_cls,
+void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *cls_m, const u64 *cls, u32 n_cls,
                           const u32 *cls_flags, const u64 *ent_off, u32 *ent, u8 *ent_dir, DevCounters *ctr)
 {
     if (!n_cls) return;
     (void)hipMemsetAsync(&ctr->huge_entries, 0, sizeof(DevCounters::Huge), s);
-    hipLaunchKernelGGL(k_class_entries, grid_for(n_cls), dim3(256), 0, s, rec, gpos, class_start, cls, n_cls, cls_flags, ent_off, ent, ent_dir, ctr);
-    hipLaunchKernelGGL(k_class_entries_huge, dim3(HUGE_GRID), dim3(256), 0, s, rec, gpos, class_start, cls, cls_flags, ent_off, ent, ent_dir, ctr);
+    hipLaunchKernelGGL(k_class_entries, grid_for(n_cls), dim3(256), 0, s, rec, gpos, cls_m, cls, n_cls, cls_flags, ent_off, ent, ent_dir, ctr);
+    hipLaunchKernelGGL(k_class_entries_huge, dim3(HUGE_GRID), dim3(256), 0, s, rec, gpos, cls_m, cls, cls_flags, ent_off, ent, ent_dir, ctr);
 }
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off, const u32 *ent,
                         const u8 *ent_dir, u8 *merge_prev)

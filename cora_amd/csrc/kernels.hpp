@@ -76,20 +76,21 @@ void launch_mixed_fix_long(hipStream_t s, const DevParams &p, const u64 *pk, u64
                            const u64 *long_runs, u32 n_long, u64 *head_mask, DevCounters *ctr);
 void launch_heads_from_keys(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *hi, const u64 *lo, const u32 *gpos,
                             u64 n, u64 *head_mask, u64 *rec);
-void launch_class_count(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, u32 n_cls, u32 *blk_nons,
-                        unsigned long long *blk_min, u64 *nons_mask /* [ceil(n_cls/256)*4] */, DevCounters *ctr);
-void launch_class_emit(hipStream_t s, const u32 *gpos, const u32 *class_start, u32 n_cls, const u64 *nons_mask,
-                       u64 *cls /* rep<<32 | class index */, const u64 *nons_off);
-void launch_nonrep_mark(hipStream_t s, const u64 *head_mask, const u32 *gpos, u64 n, u32 *nonrep);
+// per sorted record (head_mask bit i = record i opens a class): classes with >= 2 entries per block of 256 records and as a
+// mask, the first singleton, and the later members of classes marked in the (zeroed) position bitmap nonrep
+void launch_class_scan(hipStream_t s, const u64 *rec, const u32 *gpos, const u64 *head_mask, u64 n, u32 *blk_nons /* [ceil(n/256)] */,
+                       unsigned long long *blk_min, u64 *nons_mask /* [ceil(n/256)*4] */, u32 *nonrep, DevCounters *ctr);
+void launch_class_emit(hipStream_t s, const u32 *gpos, const u64 *head_mask, u64 n, const u64 *nons_mask,
+                       u64 *cls /* rep<<32 | first record */, u32 *cls_m /* records of the class */, const u64 *nons_off);
 void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words);
 void launch_rep_mask(hipStream_t s, const DevParams &p, const u32 *bad, const u32 *nonrep, u32 *rep /* may alias nonrep */);
 void launch_mask_count(hipStream_t s, const u64 *mask, u64 n_words, u32 *blk_count /* [ceil(n_words/256)] */);
 void launch_mask_emit(hipStream_t s, const u64 *mask, u64 n_words, const u64 *blk_off, u32 *pos);
 void launch_bitmap_count(hipStream_t s, const u32 *bits, u64 n_words, u32 *block_counts, u32 n_blocks);
 void launch_bitmap_emit(hipStream_t s, const u32 *bits, u64 n_words, const u64 *block_off, u32 n_blocks, u32 *out, u32 base);
-void launch_class_info(hipStream_t s, const u64 *rec, const u32 *class_start, const u64 *cls, u32 n_cls, const DevCounters *ctr,
+void launch_class_info(hipStream_t s, const u64 *rec, const u32 *cls_m, const u64 *cls, u32 n_cls, const DevCounters *ctr,
                        u32 *cls_flags, u32 *cls_entries);
-void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *class_start, const u64 *cls, u32 n_cls,
+void launch_class_entries(hipStream_t s, const u64 *rec, const u32 *gpos, const u32 *cls_m, const u64 *cls, u32 n_cls,
                           const u32 *cls_flags, const u64 *ent_off, u32 *ent /* gpos */, u8 *ent_dir, DevCounters *ctr);
 void launch_class_merge(hipStream_t s, const u64 *cls, u32 n_cls, const u32 *cls_entries, const u64 *ent_off,
                         const u32 *ent, const u8 *ent_dir, u8 *merge_prev);

@@ -110,11 +110,7 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from)
         HIPQ(hipStreamSynchronize(s));
         x.rec_s = rec_out; x.gp_s = fk.c;
     }
-    // later members of classes = the positions that are NOT representatives
-    RCQ(x.nonrep.alloc(dp.n_words));
-    HIPQ(hipMemsetAsync(x.nonrep.p, 0, dp.n_words * sizeof(u32), s));
-    launch_nonrep_mark(s, head_flag.p, x.gp_s, N, x.nonrep.p);
-    // class starts = positions of the head flags
+    // number of classes = set bits of the head mask
     {
         const u64 n_words = (N + 63) / 64, nb = (n_words + 255) / 256;
         DBuf<u32> bcnt;
@@ -123,26 +119,22 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from)
         launch_mask_count(s, head_flag.p, n_words, bcnt.p);
         if (exclusive_scan_u32_to_u64(s, bcnt.p, boff.p, nb, scr0.p, tot0.p)) return fail(100, "scan launch failed");
         HIPQ(hipMemcpyAsync(&x.NR, tot0.p, sizeof x.NR, hipMemcpyDeviceToHost, s));
-        HIPQ(hipStreamSynchronize(s));
-        RCQ(x.class_start.alloc(x.NR + 1));
-        launch_mask_emit(s, head_flag.p, n_words, boff.p, x.class_start.p);
-        const u32 n32 = (u32)N;
-        HIPQ(hipMemcpyAsync(x.class_start.p + x.NR, &n32, sizeof(u32), hipMemcpyHostToDevice, s));
-        HIPQ(hipStreamSynchronize(s));          // n32 lives on this frame
     }
-    head_flag.release();
-
-    const u32 kb = (u32)((x.NR + 255) / 256);
+    // one pass over the sorted records: classes with >= 2 entries, the first singleton, and the later members of classes
+    // (= the positions that are NOT representatives)
+    RCQ(x.nonrep.alloc(dp.n_words));
+    HIPQ(hipMemsetAsync(x.nonrep.p, 0, dp.n_words * sizeof(u32), s));
+    const u32 kb = (u32)((N + 255) / 256);
     DBuf<u32> blk_nons;
     DBuf<u64> blk_min, nons_off, scr2, tots, nons_mask;
     RCQ(blk_nons.alloc(kb)); RCQ(blk_min.alloc(kb)); RCQ(nons_off.alloc(kb)); RCQ(nons_mask.alloc((u64)kb * 4));
     RCQ(scr2.alloc(scan_scratch_elems(kb))); RCQ(tots.alloc(1));
-    launch_class_count(s, x.rec_s, x.gp_s, x.class_start.p, (u32)x.NR, blk_nons.p, (unsigned long long *)blk_min.p, nons_mask.p, job->ctr.p);
+    launch_class_scan(s, x.rec_s, x.gp_s, head_flag.p, N, blk_nons.p, (unsigned long long *)blk_min.p, nons_mask.p, x.nonrep.p, job->ctr.p);
     if (exclusive_scan_u32_to_u64(s, blk_nons.p, nons_off.p, kb, scr2.p, tots.p)) return fail(100, "scan launch failed");
     HIPQ(hipMemcpyAsync(&x.NNS, tots.p, sizeof x.NNS, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
-    RCQ(x.cls.alloc(x.NNS));
-    launch_class_emit(s, x.gp_s, x.class_start.p, (u32)x.NR, nons_mask.p, x.cls.p, nons_off.p);
+    RCQ(x.cls.alloc(x.NNS)); RCQ(x.cls_m.alloc(x.NNS));
+    launch_class_emit(s, x.gp_s, head_flag.p, N, nons_mask.p, x.cls.p, x.cls_m.p, nons_off.p);
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
     return 0;
@@ -159,12 +151,12 @@ int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p)
     RCQ(cf.alloc(x.NNS)); RCQ(p.ce.alloc(x.NNS)); RCQ(eoff.alloc(x.NNS)); RCQ(scr.alloc(scan_scratch_elems(x.NNS))); RCQ(tot.alloc(1));
     RCQ(p.cls.alloc(x.NNS));
     HIPQ(hipMemcpyAsync(p.cls.p, x.cls.p, x.NNS * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    launch_class_info(s, x.rec_s, x.class_start.p, x.cls.p, (u32)x.NNS, job->ctr.p, cf.p, p.ce.p);
+    launch_class_info(s, x.rec_s, x.cls_m.p, x.cls.p, (u32)x.NNS, job->ctr.p, cf.p, p.ce.p);
     if (exclusive_scan_u32_to_u64(s, p.ce.p, eoff.p, x.NNS, scr.p, tot.p)) return fail(100, "scan launch failed");
     HIPQ(hipMemcpyAsync(&p.NE, tot.p, sizeof p.NE, hipMemcpyDeviceToHost, s));
     HIPQ(hipStreamSynchronize(s));
     RCQ(p.ent.alloc(p.NE)); RCQ(p.edir.alloc(p.NE));
-    launch_class_entries(s, x.rec_s, x.gp_s, x.class_start.p, x.cls.p, (u32)x.NNS, cf.p, eoff.p, p.ent.p, p.edir.p, job->ctr.p);
+    launch_class_entries(s, x.rec_s, x.gp_s, x.cls_m.p, x.cls.p, (u32)x.NNS, cf.p, eoff.p, p.ent.p, p.edir.p, job->ctr.p);
     HIPQ(hipStreamSynchronize(s));
     HIPQ(hipGetLastError());
     return 0;
