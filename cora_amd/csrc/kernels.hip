@@ -658,56 +658,64 @@ __global__ __launch_bounds__(256) void k_rep_mask(DevParams p, const u32 *__rest
 }
 
 // Lists the classes with >= 2 entries as rep << 32 | index of their first record, and their sizes (records up to the next
-// class head), at offsets from the scan of blk_nons.  Same grid as k_class_scan.  The next head is in this record's mask
-// word or the one after it for all but the long classes; those (Mbp of tandem repeats make classes of 10^6 records, 16 000
-// empty mask words) are finished by the whole wave, 64 words per step.
+// class head), at offsets from the scan of blk_nons.  One thread per mask word (64 records; a thread per record spent 6 ms
+// starting 46 M waves that had nothing to list).  The next head is in the record's own mask word for all but the word's last
+// head, for which it is in the next word -- or, for the long classes (Mbp of tandem repeats make classes of 10^6 records,
+// 16 000 empty mask words), further on: those are finished by the whole wave, 64 words per step.
 __global__ __launch_bounds__(256) void k_class_emit(const u32 *__restrict__ gpos, const u64 *__restrict__ head_mask, u64 n,
                                                     const u64 *__restrict__ nons_mask, u64 *__restrict__ cls, u32 *__restrict__ cls_m,
                                                     const u64 *__restrict__ nons_off)
 {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u64 w0 = (u64)blockIdx.x * 4;
     const u64 n_words = (n + 63) >> 6;
-    const u64 bn = (w0 + wv < n_words) ? nons_mask[w0 + wv] : 0ull;   // written for every wave of k_class_scan's grid (same geometry)
-    if (!bn) return;                                                   // (wave-uniform)
-    const bool mine = (bn >> lane) & 1ull;
-    u64 next = n;                                                      // index of the next class head
-    bool found = !mine;
-    if (mine) {
-        const u64 w = i >> 6;
-        const u64 rest = lane == 63 ? 0ull : (head_mask[w] >> (lane + 1));
-        if (rest) { next = i + 1 + (u64)(__ffsll((long long)rest) - 1); found = true; }
-        else if (w + 1 < n_words) {
-            const u64 b = head_mask[w + 1];
-            if (b) { next = (w + 1) * 64 + (u64)(__ffsll((long long)b) - 1); found = true; }
-        } else found = true;                                           // the last class: it ends with the records
+    const int lane = threadIdx.x & 63;
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool in = w < n_words;
+    const u64 bn = in ? nons_mask[w] : 0ull;
+    if (!__ballot(bn != 0)) return;                                    // (wave-uniform)
+    const u64 hm = in ? head_mask[w] : 0ull;
+    u64 nxt = __shfl_down(hm, 1, 64);                                  // the next word's heads
+    if (lane == 63) nxt = (w + 1 < n_words) ? head_mask[w + 1] : 0ull;
+    u64 at = 0;
+    if (bn) {                                                          // nons_off is per 256 records = 4 words
+        at = nons_off[w >> 2];
+        for (u64 k = w & ~3ull; k < w; k++) at += (u32)__popcll(nons_mask[k]);
     }
-    u64 todo = __ballot(!found);
+    u64 pend_i = ~0ull, pend_at = 0;
+    u64 bits = bn;
+    while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        const u64 i = w * 64 + (u64)b;
+        const u64 rest = b == 63 ? 0ull : (hm >> (b + 1));
+        u64 next = n;
+        bool found = true;
+        if (rest) next = i + 1 + (u64)(__ffsll((long long)rest) - 1);
+        else if (w + 1 >= n_words) next = n;                           // the last class: it ends with the records
+        else if (nxt) next = (w + 1) * 64 + (u64)(__ffsll((long long)nxt) - 1);
+        else found = false;
+        if (found) { cls[at] = ((u64)gpos[i] << 32) | i; cls_m[at] = (u32)(next - i); }
+        else { pend_i = i; pend_at = at; }                             // (only the word's last head can be left over)
+        at++;
+    }
+    u64 todo = __ballot(pend_i != ~0ull);
     while (todo) {                                                     // long classes, one at a time, 64 mask words per step
         const int src = __ffsll((long long)todo) - 1;
-        const u64 from = (__shfl(i, src, 64) >> 6) + 2;
+        const u64 from = (__shfl(pend_i, src, 64) >> 6) + 2;
         u64 res = n;
         for (u64 base = from; base < n_words; base += 64) {
-            const u64 w = base + lane;
-            const u64 b = w < n_words ? head_mask[w] : 0ull;
-            const u64 any = __ballot(b != 0);
+            const u64 ww = base + lane;
+            const u64 bb = ww < n_words ? head_mask[ww] : 0ull;
+            const u64 any = __ballot(bb != 0);
             if (any) {
                 const int l = __ffsll((long long)any) - 1;
-                const u64 bw = __shfl(b, l, 64);
+                const u64 bw = __shfl(bb, l, 64);
                 res = (base + l) * 64 + (u64)(__ffsll((long long)bw) - 1);
                 break;
             }
         }
-        if (lane == src) next = res;
+        if (lane == src) { cls[pend_at] = ((u64)gpos[pend_i] << 32) | pend_i; cls_m[pend_at] = (u32)(res - pend_i); }
         todo &= todo - 1;
     }
-    if (!mine) return;
-    u32 pre = 0;
-    for (int w = 0; w < wv; w++) pre += (u32)__popcll(nons_mask[w0 + w]);
-    const u64 at = nons_off[blockIdx.x] + pre + (u32)__popcll(bn & ((1ull << lane) - 1ull));
-    cls[at] = ((u64)gpos[i] << 32) | (u64)i;
-    cls_m[at] = (u32)(next - i);
 }
 
 // ------------------------------------------------------------------ record mask -> positions of the set bits
@@ -2127,7 +2135,7 @@ void launch_class_scan(hipStream_t s, const u64 *rec, const u32 *gpos, const u64
 void launch_class_emit(hipStream_t s, const u32 *gpos, const u64 *head_mask, u64 n, const u64 *nons_mask, u64 *cls, u32 *cls_m,
                        const u64 *nons_off)
 {
-    if (n) hipLaunchKernelGGL(k_class_emit, grid_for(n), dim3(256), 0, s, gpos, head_mask, n, nons_mask, cls, cls_m, nons_off);
+    if (n) hipLaunchKernelGGL(k_class_emit, grid_for((n + 63) / 64), dim3(256), 0, s, gpos, head_mask, n, nons_mask, cls, cls_m, nons_off);
 }
 void launch_rep_mask_words(hipStream_t s, const u32 *valid, const u32 *nonrep, u32 *rep, u64 n_words)
 {
