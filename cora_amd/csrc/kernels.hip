@@ -374,24 +374,49 @@ __global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64
 // grouped yet: such positions are marked in mixed_mask (one ballot word per wave, like the heads; the list k_mixed_fix
 // wants comes from k_mask_count / k_mask_emit.  A shared counter here cost 12 ns per listed place: 23 ms for the 2e6
 // places of a 3e9-record sort on 40 hash bits).
+// Each wave takes 256 consecutive records in four rounds of 64 (round k, lane l: record base + 64 k + l), all loads of the
+// four rounds in flight together: with one record per thread the kernel was bound by latency x occupancy (12.8 ms for 35 GB
+// at 2.9e9 records).  A round's ballot is one mask word.
 __global__ __launch_bounds__(256) void k_same_detect(DevParams p, const u64 *__restrict__ pk, const u64 *__restrict__ rec,
                                                      const u32 *__restrict__ gpos, u64 n, int hb, u64 *__restrict__ head_mask,
                                                      u64 *__restrict__ mixed_mask)
 {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    u32 head = 0;
-    bool mixed = false;
-    if (i < n) head = 1;
-    if (i < n && i > 0 && (rec[i] >> (64 - hb)) == (rec[i - 1] >> (64 - hb))) {
-        u64 ah, al, bh, bl;
-        canonical_at(p, pk, gpos[i - 1], ah, al);
-        canonical_at(p, pk, gpos[i], bh, bl);
-        if (ah == bh && al == bl) head = 0;
-        else mixed = bh < ah || (bh == ah && bl < al);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 wbase = ((u64)blockIdx.x * 4 + wv) * 256;
+    const u64 n_pad = ((n + 255) / 256) * 256;               // the masks are sized (and read) in blocks of 256 records
+    if (wbase >= n_pad) return;                               // (wave-uniform)
+    u64 r[4];
+    u32 g[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 i = wbase + (u64)k * 64 + lane;
+        r[k] = i < n ? __builtin_nontemporal_load(rec + i) : 0ull;
+        g[k] = i < n ? gpos[i] : 0u;
     }
-    const u64 bal = __ballot(head != 0);                    // bit l of word i/64 = record 64*(i/64)+l opens a class
-    const u64 bam = __ballot(mixed);
-    if ((threadIdx.x & 63) == 0) { head_mask[i >> 6] = bal; mixed_mask[i >> 6] = bam; }
+    u64 r_before = 0;                                         // the record before this wave's first
+    u32 g_before = 0;
+    if (lane == 0 && wbase > 0 && wbase < n) { r_before = rec[wbase - 1]; g_before = gpos[wbase - 1]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 i = wbase + (u64)k * 64 + lane;
+        u64 rp = __shfl_up(r[k], 1, 64);
+        u32 gp = __shfl_up(g[k], 1, 64);
+        const u64 r_tail = k ? __shfl(r[k ? k - 1 : 0], 63, 64) : r_before;
+        const u32 g_tail = k ? __shfl(g[k ? k - 1 : 0], 63, 64) : g_before;
+        if (lane == 0) { rp = r_tail; gp = g_tail; }
+        u32 head = i < n ? 1u : 0u;
+        bool mixed = false;
+        if (i < n && i > 0 && (r[k] >> (64 - hb)) == (rp >> (64 - hb))) {
+            u64 ah, al, bh, bl;
+            canonical_at(p, pk, gp, ah, al);
+            canonical_at(p, pk, g[k], bh, bl);
+            if (ah == bh && al == bl) head = 0;
+            else mixed = bh < ah || (bh == ah && bl < al);
+        }
+        const u64 bal = __ballot(head != 0);                  // bit l of word i/64 = record 64*(i/64)+l opens a class
+        const u64 bam = __ballot(mixed);
+        if (lane == 0 && wbase + (u64)k * 64 < n_pad) { head_mask[i >> 6] = bal; mixed_mask[i >> 6] = bam; }
+    }
 }
 
 // One thread per listed position.  The run of equal truncated hashes around it is found by binary search (the records
@@ -580,48 +605,55 @@ __device__ __forceinline__ bool key_is_palindrome(int K, u64 hi, u64 lo)
 // members are few (the repeated K-mers), so they are what gets marked, by atomics, in a zeroed bitmap.
 // (Round 2 first ran this per CLASS over an array of class starts: start -> record -> position was a chain of dependent
 //  gathers, 14.9 ms at 2.6e9 classes, plus 5.4 ms for marking the later members and 1.9 ms for listing the starts.)
+// Each wave takes 256 consecutive records in four rounds of 64, all loads in flight together (as k_same_detect): one wave =
+// one entry of blk_nons / blk_min, one round = one mask word.
 __global__ __launch_bounds__(256) void k_class_scan(const u64 *__restrict__ rec, const u32 *__restrict__ gpos,
                                                     const u64 *__restrict__ head_mask, u64 n, u32 *__restrict__ blk_nons,
                                                     unsigned long long *__restrict__ blk_min, u64 *__restrict__ nons_mask,
                                                     u32 *__restrict__ nonrep)
 {
-    __shared__ u32 s_nons[4];
-    __shared__ unsigned long long s_min[4];
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    bool nons = false;
+    const u64 wid = (u64)blockIdx.x * 4 + wv;                 // this wave's block of 256 records
+    const u64 wbase = wid * 256;
+    if (wbase >= n) return;                                    // (wave-uniform; the masks and partials cover ceil(n / 256) blocks)
+    u64 r[4], hw[5];
+    u32 g[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 i = wbase + (u64)k * 64 + lane;
+        r[k] = i < n ? __builtin_nontemporal_load(rec + i) : 0ull;
+        g[k] = i < n ? __builtin_nontemporal_load(gpos + i) : 0u;
+        hw[k] = head_mask[(wbase >> 6) + k];                   // this round's 64 head bits
+    }
+    hw[4] = (wbase + 256 < n) ? head_mask[(wbase >> 6) + 4] : 1ull;      // does the record after the wave's last open a class?  (past the end: yes)
     unsigned long long key = ~0ull;
-    const u64 hw = (i - lane < n) ? head_mask[i >> 6] : 0ull;              // this wave's 64 head bits
-    // does record i + 1 open a class?  (lane 63 asks the next word; past the end counts as "yes")
-    u64 nw = 1ull;
-    if (lane == 63 && i + 1 < n) nw = head_mask[(i >> 6) + 1];
-    if (i < n) {
-        const bool head = (hw >> lane) & 1ull;
-        const u64 r = rec[i];
-        const u32 g = gpos[i];
-        if (head) {
-            const bool next_opens = (i + 1 >= n) || (lane == 63 ? (nw & 1ull) : ((hw >> (lane + 1)) & 1ull));
-            const u32 fl = (u32)r & 0xFFu;
-            if (next_opens && !(fl & 2u)) key = ((unsigned long long)(fl >> 2) << 32) | g;
-            else nons = true;
-        } else {
-            atomicOr(&nonrep[g >> 5], 1u << (31 - (g & 31)));
+    u32 cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 i = wbase + (u64)k * 64 + lane;
+        bool nons = false;
+        if (i < n) {
+            if ((hw[k] >> lane) & 1ull) {
+                const bool next_opens = (i + 1 >= n) || (lane == 63 ? (hw[k + 1] & 1ull) : ((hw[k] >> (lane + 1)) & 1ull));
+                const u32 fl = (u32)r[k] & 0xFFu;
+                if (next_opens && !(fl & 2u)) {
+                    const unsigned long long mine = ((unsigned long long)(fl >> 2) << 32) | g[k];
+                    key = mine < key ? mine : key;
+                } else nons = true;
+            } else {
+                atomicOr(&nonrep[g[k] >> 5], 1u << (31 - (g[k] & 31)));
+            }
         }
+        const u64 bn = __ballot(nons);
+        cnt += (u32)__popcll(bn);
+        if (lane == 0) nons_mask[(wbase >> 6) + k] = bn;       // kept for k_class_emit
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(key, o, 64);
         key = other < key ? other : key;
     }
-    const u64 bn = __ballot(nons);
-    if (lane == 0) { s_nons[wv] = (u32)__popcll(bn); s_min[wv] = key; nons_mask[i >> 6] = bn; }   // kept for k_class_emit
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        blk_nons[blockIdx.x] = s_nons[0] + s_nons[1] + s_nons[2] + s_nons[3];
-        unsigned long long m = s_min[0];
-        for (int w = 1; w < 4; w++) m = s_min[w] < m ? s_min[w] : m;
-        blk_min[blockIdx.x] = m;
-    }
+    if (lane == 0) { blk_nons[wid] = cnt; blk_min[wid] = key; }
 }
 
 __global__ __launch_bounds__(256) void k_min_u64(const unsigned long long *__restrict__ in, u64 n, unsigned long long *out)
@@ -2106,7 +2138,7 @@ void launch_contig_scan(hipStream_t s, const DevParams &p, const u32 *bad, DevCo
 void launch_same_detect(hipStream_t s, const DevParams &p, const u64 *pk, const u64 *rec, const u32 *gpos, u64 n, int hb,
                         u64 *head_mask, u64 *mixed_mask)
 {
-    if (n) hipLaunchKernelGGL(k_same_detect, grid_for(n), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_mask, mixed_mask);
+    if (n) hipLaunchKernelGGL(k_same_detect, grid_for((n + 3) / 4), dim3(256), 0, s, p, pk, rec, gpos, n, hb, head_mask, mixed_mask);      // 1024 records per block
 }
 void launch_mixed_fix(hipStream_t s, const DevParams &p, const u64 *pk, u64 *rec, u32 *gpos, u64 n, int hb, u64 *head_mask, const u32 *mixed_list,
                       u32 n_mixed, u32 *claim, u64 *long_runs, u32 long_cap, DevCounters *ctr)
@@ -2129,7 +2161,7 @@ void launch_class_scan(hipStream_t s, const u64 *rec, const u32 *gpos, const u64
 {
     if (!n) return;
     const dim3 g = grid_for(n);
-    hipLaunchKernelGGL(k_class_scan, g, dim3(256), 0, s, rec, gpos, head_mask, n, blk_nons, blk_min, nons_mask, nonrep);
+    hipLaunchKernelGGL(k_class_scan, grid_for((n + 3) / 4), dim3(256), 0, s, rec, gpos, head_mask, n, blk_nons, blk_min, nons_mask, nonrep);     // 1024 records per block
     hipLaunchKernelGGL(k_min_u64, dim3(g.x < 64 ? g.x : 64), dim3(256), 0, s, blk_min, (u64)g.x, &ctr->first_singleton_key);
 }
 void launch_class_emit(hipStream_t s, const u32 *gpos, const u64 *head_mask, u64 n, const u64 *nons_mask, u64 *cls, u32 *cls_m,
