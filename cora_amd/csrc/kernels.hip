@@ -1052,32 +1052,48 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
     __syncthreads();
     u64 *const outs[4] = {out0, out1, out2, out3};
     const u64 base = (u64)blockIdx.x * 256 * per_thread;    // one tile of the sort that follows (16 or 32 records per thread)
-#pragma unroll 4
-    for (int k = 0; k < per_thread; k++) {
-        const u64 r = base + (u64)k * 256 + tid;
-        if (r >= n_reps) break;
-        const u32 g = reps[r];
-        u64 hi, lo;
-        load_window(p, pk, g, hi, lo);
-        const int sh = 128 - 2 * p.K;                     // 0 .. 62
-        const u64 tail = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-        u32 fwc[NS], rcc[NS];
+    // four records at a time: their positions first, then their windows, then the codes -- so that four gathers are in
+    // flight per thread instead of one (position -> window is a dependent chain; per_thread is a multiple of 4)
+    for (int k0 = 0; k0 < per_thread; k0 += 4) {
+        u32 gq[4];
+        u64 hq[4], lq[4];
 #pragma unroll
-        for (int s = 0; s < NS; s++) { fwc[s] = seed_code_fixed<NS>(hi, tail, s, p.seed_q); rcc[s] = rc_code(fwc[s]); }
+        for (int j = 0; j < 4; j++) {
+            const u64 r = base + (u64)(k0 + j) * 256 + tid;
+            gq[j] = r < n_reps ? __builtin_nontemporal_load(reps + r) : 0u;
+        }
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            if (only >= 0 && s != only) continue;             // one seed per launch (large references: memory)
-            const bool fwd = fwc[s] <= rcc[s];
-            const u32 c = fwd ? fwc[s] : rcc[s];
-            outs[s][r] = ((u64)c << 32) | g;
-            atomicAdd(&h[s][c & 255u], 1u);
-            if (sk.on) {                                       // (an array that is not wanted is null: the sharded flow moves b only)
-                const u32 o1 = fwd ? fwc[(s + 1) % NS] : rcc[(s + 1) % NS];
-                if (NS == 2) { if (sk.c[s]) sk.c[s][r] = o1; }
-                else {
-                    const u32 o2 = fwd ? fwc[(s + 2) % NS] : rcc[(s + 2) % NS];
-                    if (sk.b[s]) sk.b[s][r] = ((u64)o1 << 32) | o2;
-                    if (NS == 4 && sk.c[s]) sk.c[s][r] = fwd ? fwc[(s + 3) % NS] : rcc[(s + 3) % NS];
+        for (int j = 0; j < 4; j++) {
+            const u64 r = base + (u64)(k0 + j) * 256 + tid;
+            hq[j] = lq[j] = 0;
+            if (r < n_reps) load_window(p, pk, gq[j], hq[j], lq[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u64 r = base + (u64)(k0 + j) * 256 + tid;
+            if (r >= n_reps) break;
+            const u32 g = gq[j];
+            const u64 hi = hq[j], lo = lq[j];
+            const int sh = 128 - 2 * p.K;                     // 0 .. 62
+            const u64 tail = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+            u32 fwc[NS], rcc[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) { fwc[s] = seed_code_fixed<NS>(hi, tail, s, p.seed_q); rcc[s] = rc_code(fwc[s]); }
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                if (only >= 0 && s != only) continue;             // one seed per launch (large references: memory)
+                const bool fwd = fwc[s] <= rcc[s];
+                const u32 c = fwd ? fwc[s] : rcc[s];
+                outs[s][r] = ((u64)c << 32) | g;
+                atomicAdd(&h[s][c & 255u], 1u);
+                if (sk.on) {                                       // (an array that is not wanted is null: the sharded flow moves b only)
+                    const u32 o1 = fwd ? fwc[(s + 1) % NS] : rcc[(s + 1) % NS];
+                    if (NS == 2) { if (sk.c[s]) sk.c[s][r] = o1; }
+                    else {
+                        const u32 o2 = fwd ? fwc[(s + 2) % NS] : rcc[(s + 2) % NS];
+                        if (sk.b[s]) sk.b[s][r] = ((u64)o1 << 32) | o2;
+                        if (NS == 4 && sk.c[s]) sk.c[s][r] = fwd ? fwc[(s + 3) % NS] : rcc[(s + 3) % NS];
+                    }
                 }
             }
         }
