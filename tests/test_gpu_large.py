@@ -32,6 +32,7 @@ def _build_and_check(contigs, K, d, p, t, tmp_path, repeat=True, L=False):
     job.run()
     e, en, x, xn = job.tables()
     st = job.stats()
+    st["exact_sha256"], st["inexact_sha256"] = hashlib.sha256(e).hexdigest(), hashlib.sha256(x).hexdigest()
     if repeat:                                           # a second build of the same job: the same bytes
         job.run()
         e2, en2, x2, xn2 = job.tables()
@@ -56,6 +57,11 @@ def _build_and_check(contigs, K, d, p, t, tmp_path, repeat=True, L=False):
     return st, r.stdout
 
 
+# the tables of workload_grch38_like(38, 1.0), K = 50, d = 2, -p 10 -t 8: what every build of it must produce (bench.py prints the
+# same two hashes in `tables_of_last_step`); test_config2_grch38_sized_reference checks these very bytes with table_check
+CONFIG2_SHA256 = ("2abe201b61f505d066eb1f6416c168e8a59d3c01d3c95c610f0020ba5c08e8cd", "3f366fdf22b788996899ddc09a15d42d2d78d63352be72e150d425d227c42be4")
+
+
 def test_config2_grch38_sized_reference(tmp_path):
     """3.09 Gbp in 25 contigs (bench.py's workload): the exact sort on 40 hash bits with 2e6 collision places to repair, the sketches
     switched on by the size itself (not by CORA_SKETCH), per-seed record generation, the balanced candidate kernel."""
@@ -66,6 +72,29 @@ def test_config2_grch38_sized_reference(tmp_path):
     assert st["seed_sketch"] == 1 and st["full_key_fallback"] == 0 and st["hash_mixed_runs"] > 0
     assert st["verify_slots"] < st["candidate_pairs"] // 10          # the sketches dismissed the chance partners
     assert st["hom_pairs"] > 100_000_000 and st["inexact_nodes"] > 10_000_000
+    assert (st["exact_sha256"], st["inexact_sha256"]) == CONFIG2_SHA256
+
+
+@pytest.mark.parametrize("keep_own", ["1", "0"])
+def test_config2_two_ranks_sharing_the_gpu_build_the_same_tables(keep_own, monkeypatch):
+    """BASELINE configs[2] is quoted on 8 GPUs; a one-GPU box can only rehearse it: the in-process multi-GPU flow
+    (cora_hip_job_run_multi) with two ranks on the one device, at the full 3.09 Gbp, must produce the bytes of the
+    single-GPU build -- with every rank scanning all positions and keeping its own records (what 2 to 4 GPUs do) and with
+    the records exchanged (what more GPUs do; here the "links" are device-local copies)."""
+    hip.init(0)
+    monkeypatch.setenv("CORA_SHARD_FILTER", keep_own)
+    contigs = synth.workload_grch38_like(38, 1.0)
+    image, W, geom = synth.fasta_image(contigs, 60)
+    del contigs
+    job = hip.Job(50, 2, helpers.split_path("phys", 10), helpers.split_path("par", 8))
+    job.set_reference(image, W, geom)
+    del image
+    job.run_multi(2, [0, 0])
+    e, en, x, xn = job.tables()
+    st = job.stats()
+    job.close()
+    assert (hashlib.sha256(e).hexdigest(), hashlib.sha256(x).hexdigest()) == CONFIG2_SHA256
+    assert st["kmers"] > 2_900_000_000 and st["hom_pairs"] > 100_000_000
 
 
 def test_config3_k64_d3_gbp(tmp_path):
