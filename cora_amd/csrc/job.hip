@@ -255,7 +255,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         memset(&sk, 0, sizeof sk);
         // Chance collisions of 32-bit seed codes grow with NR^2 / 2^32: from a few hundred million representatives on they
         // dominate verification, and carrying the other seeds' codes through the sort (4 d bytes per record) pays for
-        // itself: k_verify then dismisses partners from the sorted records alone, without touching the genome.
+        // itself: the candidate kernels then dismiss partners from the sorted records alone, without touching the genome.
         const bool use_sketch = job->sketch_mode >= 0 ? job->sketch_mode != 0 : NR > SKETCH_MIN_REPS;
         sk.on = use_sketch;
         const u32 tile_recs = radix_sort_tile_records(use_sketch && dp.nseeds >= 3, use_sketch && dp.nseeds != 3);

@@ -1036,7 +1036,7 @@ __device__ __forceinline__ u32 seed_code_fixed(u64 hi, u64 tail, int s /*0-based
 // orientation that made this seed's code canonical (the code of seed s' of the reverse complement is rc_code of the
 // forward one: seeds are mirror-symmetric position sets, HTS:2015-2066).  Two records with the same canonical, non-
 // palindromic code are the same K-mer positions in that orientation, so the number of differing bases between their
-// sketches is exactly the number of mismatches inside the other seeds: k_verify dismisses a partner on it without
+// sketches is exactly the number of mismatches inside the other seeds: the candidate kernels dismiss a partner on it without
 // touching the genome.  For K = 50, d = 2 the three seeds cover 48 of the 50 bases.  Layout: NS = 2: one code in skc;
 // NS = 3: two codes in skb (first other seed in the high word); NS = 4: two in skb, the third in skc.
 template <int NS>
