@@ -1860,24 +1860,43 @@ __global__ __launch_bounds__(256) void k_run_dirty(const u32 *__restrict__ node_
     if (nd < n_nodes && node_tie[nd]) run_dirty[run_excl[nd] + run_head[nd] - 1] = 1u;
 }
 
-// bytes of every device-written list (0 for host lists and for lists whose items were all absorbed)
+// bytes of every device-written list (0 for host lists and for lists whose items were all absorbed).  A block takes 256
+// consecutive lists: their items are one contiguous range, which the whole block reads coalesced; an item that survived the
+// block merge finds its list by a search over the 257 list starts in LDS.  (One thread walking each list took 7.2 ms at
+// 3.6e7 lists: a wave waited for its longest list, and lists are 1 to thousands of items long.)
 __global__ __launch_bounds__(256) void k_node_size(DevParams p, int cw, const u32 *__restrict__ node_start, const int16_t *__restrict__ blen,
                                                    const u64 *__restrict__ run_excl, const u32 *__restrict__ run_head,
                                                    const u32 *__restrict__ run_dirty, u32 n_nodes, u32 *__restrict__ size,
-                                                   u32 *__restrict__ hflag, u32 *__restrict__ hcnt, DevCounters *ctr)
+                                                   u32 *__restrict__ hflag, u32 *__restrict__ hcnt, u32 *__restrict__ blk_counts /* [2 * blocks] */)
 {
+    __shared__ u32 s_start[257], s_alive[256];
     __shared__ u32 s_emit[4], s_big[4];
-    const u32 nd = blockIdx.x * 256 + threadIdx.x;
+    const u32 n0 = blockIdx.x * 256;
+    const u32 nd = n0 + threadIdx.x;
+    const u32 n_here = n_nodes - n0 < 256u ? n_nodes - n0 : 256u;
+    // the dependent look-up of this list's run first, so that it is in flight beside the item loop
+    bool dirty = false;
+    if (nd < n_nodes) dirty = run_dirty[run_excl[nd] + run_head[nd] - 1] != 0;
+    s_alive[threadIdx.x] = 0;
+    if (threadIdx.x <= n_here) s_start[threadIdx.x] = node_start[n0 + threadIdx.x];
+    if (threadIdx.x == 0 && n_here == 256u) s_start[256] = node_start[n0 + 256];
+    __syncthreads();
+    const u32 A = s_start[0], B = s_start[n_here];
+    for (u32 k = A + threadIdx.x; k < B; k += 256) {
+        if (blen[k] == -1) continue;
+        u32 lo = 0, hi = n_here;                               // the list j with s_start[j] <= k < s_start[j + 1]
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_start[mid] <= k) lo = mid; else hi = mid; }
+        atomicAdd(&s_alive[lo], 1u);
+    }
+    __syncthreads();
     bool emitted = false, big = false;
     if (nd < n_nodes) {
-        const u32 a = node_start[nd], b = node_start[nd + 1], cnt = b - a;
-        const bool dirty = run_dirty[run_excl[nd] + run_head[nd] - 1] != 0;
+        const u32 cnt = s_start[threadIdx.x + 1] - s_start[threadIdx.x];
         const bool host = dirty || cnt >= (1u << DS_KEY_SHIFT);
         big = cnt > 16;
         u32 sz = 0;
         if (!host) {
-            u32 alive = 0;
-            for (u32 k = a; k < b; k++) alive += (blen[k] != -1) ? 1u : 0u;
+            const u32 alive = s_alive[threadIdx.x];
             if (alive) sz = (u32)(cw + 4) + alive * (u32)(1 + cw + 4 + p.d + 2) + 1u;
             emitted = alive != 0;
         }
@@ -1888,10 +1907,26 @@ __global__ __launch_bounds__(256) void k_node_size(DevParams p, int cw, const u3
     const u64 bal = __ballot(emitted), bbig = __ballot(big);
     if ((threadIdx.x & 63) == 0) { s_emit[threadIdx.x >> 6] = (u32)__popcll(bal); s_big[threadIdx.x >> 6] = (u32)__popcll(bbig); }
     __syncthreads();
+    if (threadIdx.x == 0) {                                    // per-block partials: two same-address atomics per block were half of this kernel's 7.2 ms
+        blk_counts[2 * blockIdx.x] = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3];
+        blk_counts[2 * blockIdx.x + 1] = s_big[0] + s_big[1] + s_big[2] + s_big[3];
+    }
+}
+
+// emitted_nodes / big_nodes += the per-block pairs of k_node_size (one atomic per field and workgroup of a 64-workgroup grid)
+__global__ __launch_bounds__(256) void k_node_counts(const u32 *__restrict__ blk_counts, u32 n_blocks, DevCounters *ctr)
+{
+    __shared__ unsigned long long s_e[4], s_b[4];
+    unsigned long long e = 0, b = 0;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n_blocks; i += gridDim.x * 256) { e += blk_counts[2 * i]; b += blk_counts[2 * i + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = e; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const u32 t = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3], tb = s_big[0] + s_big[1] + s_big[2] + s_big[3];
-        if (t) atomicAdd(&ctr->emitted_nodes, (unsigned long long)t);
-        if (tb) atomicAdd(&ctr->big_nodes, (unsigned long long)tb);
+        e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; b = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+        if (e) atomicAdd(&ctr->emitted_nodes, e);
+        if (b) atomicAdd(&ctr->big_nodes, b);
     }
 }
 
@@ -2116,10 +2151,12 @@ void launch_run_dirty(hipStream_t s, const u32 *node_tie, const u64 *run_excl, c
     if (n_nodes) hipLaunchKernelGGL(k_run_dirty, grid_for(n_nodes), dim3(256), 0, s, node_tie, run_excl, run_head, n_nodes, run_dirty);
 }
 void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node_start, const int16_t *blen, const u64 *run_excl,
-                      const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, DevCounters *ctr)
+                      const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, u32 *blk_counts, DevCounters *ctr)
 {
-    if (n_nodes) hipLaunchKernelGGL(k_node_size, grid_for(n_nodes), dim3(256), 0, s, p, cw, node_start, blen, run_excl, run_head, run_dirty,
-                                    n_nodes, size, hflag, hcnt, ctr);
+    if (!n_nodes) return;
+    const dim3 g = grid_for(n_nodes);
+    hipLaunchKernelGGL(k_node_size, g, dim3(256), 0, s, p, cw, node_start, blen, run_excl, run_head, run_dirty, n_nodes, size, hflag, hcnt, blk_counts);
+    hipLaunchKernelGGL(k_node_counts, dim3(g.x < 64 ? g.x : 64), dim3(256), 0, s, blk_counts, g.x, ctr);
 }
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 node_lo, u32 node_hi, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,

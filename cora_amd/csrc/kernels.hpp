@@ -129,7 +129,7 @@ void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cl
 void launch_node_class(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *node_start, u32 n_nodes, u32 *run_head, u32 *node_tie);
 void launch_run_dirty(hipStream_t s, const u32 *node_tie, const u64 *run_excl, const u32 *run_head, u32 n_nodes, u32 *run_dirty);
 void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node_start, const int16_t *blen, const u64 *run_excl,
-                      const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, DevCounters *ctr);
+                      const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, u32 *blk_counts /* [2 * ceil(n_nodes / 256)] scratch */, DevCounters *ctr);
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 node_lo, u32 node_hi /* lists node_lo .. node_hi-1 */, const u32 *size, const u64 *off,
                        const u32 *hflag, const u64 *hidx, const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen,

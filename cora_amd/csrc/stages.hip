@@ -368,7 +368,9 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         if (exclusive_scan_u32_to_u64(s, run_head.p, run_excl.p, nn, scr.p, nullptr)) return fail(100, "scan launch failed");
         HIPQ(hipMemsetAsync(run_dirty.p, 0, (size_t)nn * sizeof(u32), s));
         launch_run_dirty(s, node_tie.p, run_excl.p, run_head.p, nn, run_dirty.p);
-        launch_node_size(s, dp, cw, nstart.p, blen.p, run_excl.p, run_head.p, run_dirty.p, nn, nsize.p, hflag.p, hcnt.p, job->ctr.p);
+        DBuf<u32> size_counts;
+        RCQ(size_counts.alloc(2 * (((size_t)nn + 255) / 256)));
+        launch_node_size(s, dp, cw, nstart.p, blen.p, run_excl.p, run_head.p, run_dirty.p, nn, nsize.p, hflag.p, hcnt.p, size_counts.p, job->ctr.p);
         if (exclusive_scan_u32_to_u64(s, nsize.p, noff.p, nn, scr.p, tots.p)) return fail(100, "scan launch failed");
         if (exclusive_scan_u32_to_u64(s, hflag.p, hidx.p, nn, scr.p, tots.p + 1)) return fail(100, "scan launch failed");
         if (exclusive_scan_u32_to_u64(s, hcnt.p, hoff.p, nn, scr.p, tots.p + 2)) return fail(100, "scan launch failed");
