@@ -54,6 +54,10 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
     make_seed_template(hg.K, hg.d, hg.tmpl, &hg.seed_q);
     if (const char *e = getenv("CORA_SKETCH")) j->sketch_mode = atoi(e) != 0;
     if (const char *e = getenv("CORA_HASH_BITS")) { int v = atoi(e); if (v >= 8 && v <= 56) j->hash_bits = v & ~7; }
+    {   // host threads of the table finish (serialising the lists with tied targets, moving the byte stream into place)
+        const unsigned hc = std::thread::hardware_concurrency();
+        j->host_threads = hc ? (int)(hc < 16u ? hc : 16u) : 8;
+    }
     if (const char *e = getenv("CORA_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) j->host_threads = v; }
     if (hipStreamCreate(&j->stream) != hipSuccess) { delete j; return fail(100, "hipStreamCreate failed"); }
     for (auto &e : j->ev) if (hipEventCreate(&e) != hipSuccess) { delete j; return fail(100, "hipEventCreate failed"); }
@@ -206,10 +210,10 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         // the packed reference starts its way to the host now (0.25 B per base over PCIe beside 0.8 s of kernels): lists
         // with tied targets are finished there and read their K-mers from it (st_items_finish)
         RCQ(job->h_packed.reserve(packed_words));
-        HIPQ(hipEventRecord(job->ev_copy[4], s));
-        HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[4], 0));
+        HIPQ(hipEventRecord(job->ev_copy[EV_PACKED_READY], s));
+        HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[EV_PACKED_READY], 0));
         HIPQ(hipMemcpyAsync(job->h_packed.p, job->pk.p, packed_words * sizeof(u64), hipMemcpyDeviceToHost, job->copy_stream));
-        HIPQ(hipEventRecord(job->ev_copy[9], job->copy_stream));
+        HIPQ(hipEventRecord(job->ev_copy[EV_PACKED_ARRIVED], job->copy_stream));
         job->packed_in_flight = true;
     }
     ExactLocal x;

@@ -138,6 +138,9 @@ struct PoolScope {                                       // binds a job's pool t
     ~PoolScope() { g_pool = prev; }
 };
 
+constexpr int STREAM_PIECES = 8;          // the byte stream of <Inexact> is written and sent in this many pieces (st_items_finish)
+constexpr int EV_WRITTEN = 0, EV_ARRIVED = STREAM_PIECES, EV_PACKED_READY = 2 * STREAM_PIECES, EV_PACKED_ARRIVED = 2 * STREAM_PIECES + 1;
+
 struct cora_hip_job {
     cora_hip_params prm;
     HostGenome hg;
@@ -147,7 +150,9 @@ struct cora_hip_job {
     // Copies to the host that run beside the kernels (their own stream): the packed reference, which the host part of
     // <Inexact> reads, leaves right after k_pack; the <Inexact> byte stream leaves in pieces while k_node_write writes the rest.
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copy[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0-3 piece written, 4 packed, 5-8 piece arrived, 9 packed reference arrived
+    // events of the copy stream: piece c of the <Inexact> byte stream written (EV_WRITTEN + c) / arrived on the host (EV_ARRIVED + c),
+    // the packed reference ready to leave / arrived
+    hipEvent_t ev_copy[2 * STREAM_PIECES + 2] = {};
     bool packed_in_flight = false;        // h_packed is being filled (or is full) for this run
     bool have_ref = false;
     uint64_t genome_bases = 0;

@@ -376,8 +376,9 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         if (exclusive_scan_u32_to_u64(s, hcnt.p, hoff.p, nn, scr.p, tots.p + 2)) return fail(100, "scan launch failed");
         u64 totals[3] = {0, 0, 0};                          // stream bytes, host lists, their items
         HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
-        // the byte stream is written and sent in up to four pieces of consecutive lists: where each piece starts
-        constexpr int PIECES = 4;
+        // the byte stream is written and sent in up to STREAM_PIECES pieces of consecutive lists: where each piece starts.  (What the
+        // host still has to do when the device is done is the last piece's copy and its move into place: 7 ms with four pieces.)
+        constexpr int PIECES = STREAM_PIECES;
         const int pieces = nn >= (1u << 20) ? PIECES : 1;
         u32 piece_node[PIECES + 1];
         u64 piece_off[PIECES + 1];
@@ -423,24 +424,24 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         for (int c = 0; c < pieces; c++) {
             launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, piece_node[c], piece_node[c + 1], nsize.p, noff.p, hflag.p, hidx.p, hoff.p,
                               node_tie.p, stream.p, hnodes.p, hk.p, hm.p, hbl.p, ord.p, 2);
-            HIPQ(hipEventRecord(job->ev_copy[c], s));
-            HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[c], 0));
+            HIPQ(hipEventRecord(job->ev_copy[EV_WRITTEN + c], s));
+            HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[EV_WRITTEN + c], 0));
             if (piece_off[c + 1] > piece_off[c])
                 HIPQ(hipMemcpyAsync(job->h_stream.p + piece_off[c], stream.p + piece_off[c], piece_off[c + 1] - piece_off[c], hipMemcpyDeviceToHost,
                                     job->copy_stream));
-            HIPQ(hipEventRecord(job->ev_copy[5 + c], job->copy_stream));
+            HIPQ(hipEventRecord(job->ev_copy[EV_ARRIVED + c], job->copy_stream));
             arrival.upto.push_back((size_t)piece_off[c + 1]);
         }
         HIPQ(hipGetLastError());
         arrival.wait = [job](size_t c) {
             static const bool trace = getenv("CORA_TRACE") != nullptr;
             const auto w0 = std::chrono::steady_clock::now();
-            const bool ok = hipEventSynchronize(job->ev_copy[5 + c]) == hipSuccess;
+            const bool ok = hipEventSynchronize(job->ev_copy[EV_ARRIVED + c]) == hipSuccess;
             if (trace) fprintf(stderr, "[cora]   stream piece %zu: waited %.3f ms for it\n", c, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
             return ok;
         };
         have_arrival = true;
-        if (packed_host.n && job->packed_in_flight) HIPQ(hipEventSynchronize(job->ev_copy[9]));      // (sent 0.7 s ago)
+        if (packed_host.n && job->packed_in_flight) HIPQ(hipEventSynchronize(job->ev_copy[EV_PACKED_ARRIVED]));      // (sent 0.7 s ago)
         trace_mark(job, "items: copies queued", 7);
         // list starts of the compacted host items
         RCQ(job->h_node_start.reserve(totals[1] + 1));
