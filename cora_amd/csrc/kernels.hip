@@ -1176,9 +1176,11 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
                                                     u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
                                                     PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c,
                                                     u64 *__restrict__ staged /* [blocks * VT_QUOTA] */, u8 *__restrict__ blk_staged,
-                                                    const u8 *__restrict__ blk_mode /* 1: k_candidates_pairs has done this tile (null: none) */)
+                                                    const u8 *__restrict__ blk_mode /* 1: k_candidates_pairs has done this tile (null: none) */,
+                                                    const u32 *__restrict__ tiles /* the tiles to do, one per workgroup (null: workgroup b does tile b) */)
 {
-    if (blk_mode && blk_mode[blockIdx.x]) return;
+    const u32 tile = tiles ? tiles[blockIdx.x] : blockIdx.x;
+    if (blk_mode && blk_mode[tile]) return;
     __shared__ u64 s_key[VT_TILE + VT_HALO];
     __shared__ u64 s_b[SKB ? VT_TILE + VT_HALO : 1];
     __shared__ u32 s_c[SKC ? VT_TILE + VT_HALO : 1];
@@ -1189,15 +1191,15 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
     __shared__ u32 l4[4];
     __shared__ u64 c4[4];
     const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * VT_TILE;
+    const u64 base = (u64)tile * VT_TILE;
     u64 at = 0;
     u32 mine = 1;
     bool spill = false;                                      // counting pass: this thread's slots cannot all be kept
     if (!WRITE && tid == 0) s_n = 0;                         // (published by the barrier behind the tile loads)
     if (WRITE) {
-        if (blk_slots[blockIdx.x] == 0 || blk_staged[blockIdx.x]) return;   // nothing worth a look in this tile, or the counting pass kept it all (uniform)
-        mine = cnt_slots[(u64)blockIdx.x * 256 + tid];
-        at = blk_off[blockIdx.x] + block_excl_scan_u32(mine, l4, nullptr);
+        if (blk_slots[tile] == 0 || blk_staged[tile]) return;   // nothing worth a look in this tile, or the counting pass kept it all (uniform)
+        mine = cnt_slots[(u64)tile * 256 + tid];
+        at = blk_off[tile] + block_excl_scan_u32(mine, l4, nullptr);
     }
     const u64 lo = base >= (u64)VT_HALO ? base - VT_HALO : 0;       // first record held in LDS, at slot `first`
     const int first = (int)(VT_HALO - (base - lo));
@@ -1304,13 +1306,13 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
         if (keep_all) {                                                     // the tile's slots, in thread order, at its place in the staging array
             if ((u32)tid < total) {
                 const u32 e = s_val[WRITE ? 0 : tid], o = s_own[WRITE ? 0 : tid];
-                staged[(u64)blockIdx.x * VT_QUOTA + s_pre[WRITE ? 0 : (o >> 8)] + (o & 255u)] = ((u64)(u32)s_key[e >> 16] << 32) | (u32)s_key[e & 0xFFFFu];
+                staged[(u64)tile * VT_QUOTA + s_pre[WRITE ? 0 : (o >> 8)] + (o & 255u)] = ((u64)(u32)s_key[e >> 16] << 32) | (u32)s_key[e & 0xFFFFu];
             }
-        } else cnt_slots[(u64)blockIdx.x * 256 + tid] = nslot;              // the WRITE pass walks this tile again
+        } else cnt_slots[(u64)tile * 256 + tid] = nslot;              // the WRITE pass walks this tile again
         if (tid == 0) {
-            blk_slots[blockIdx.x] = total;
-            blk_staged[blockIdx.x] = keep_all ? 1 : 0;
-            blk_cand[blockIdx.x] = c4[0] + c4[1] + c4[2] + c4[3];
+            blk_slots[tile] = total;
+            blk_staged[tile] = keep_all ? 1 : 0;
+            blk_cand[tile] = c4[0] + c4[1] + c4[2] + c4[3];
         }
     }
 }
@@ -1359,8 +1361,9 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
                                                           u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
                                                           PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c,
                                                           u64 *__restrict__ staged /* [blocks * VT_QUOTA] */, u8 *__restrict__ blk_staged,
-                                                          u8 *__restrict__ blk_mode)
+                                                          u8 *__restrict__ blk_mode, const u32 *__restrict__ tiles /* as in k_candidates */)
 {
+    const u32 tile = tiles ? tiles[blockIdx.x] : blockIdx.x;
     __shared__ u64 s_key[VT_TILE + VT_HALO];
     __shared__ u64 s_b[SKB ? VT_TILE + VT_HALO : 1];
     __shared__ u32 s_c[SKC ? VT_TILE + VT_HALO : 1];
@@ -1370,9 +1373,9 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
     __shared__ u32 s_seg[4], s_w[4];
     __shared__ u32 s_n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u64 base = (u64)blockIdx.x * VT_TILE;
+    const u64 base = (u64)tile * VT_TILE;
     if (WRITE) {
-        if (!blk_mode[blockIdx.x] || blk_slots[blockIdx.x] == 0 || blk_staged[blockIdx.x]) return;    // not ours, nothing found, or all kept
+        if (!blk_mode[tile] || blk_slots[tile] == 0 || blk_staged[tile]) return;    // not ours, nothing found, or all kept
     }
     if (!WRITE && tid == 0) s_n = 0;
     const u64 lo = base >= (u64)VT_HALO ? base - VT_HALO : 0;       // first record held in LDS, at slot `first`
@@ -1443,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
     }
     irregular = __syncthreads_or(irregular);
     if (irregular) {
-        if (!WRITE && tid == 0) blk_mode[blockIdx.x] = 0;
+        if (!WRITE && tid == 0) blk_mode[tile] = 0;
         return;
     }
     // ---- 2. pairs of the wave, 64 at a time ----
@@ -1456,8 +1459,8 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
         for (int j = 0; j < 8; j++) { pr[j] = x; x += r[j]; }
     }
     u32 seg_pre = 0;                                                // WRITE: slots of the waves before this one
-    if (WRITE) for (int w = 0; w < wv; w++) seg_pre += cnt_slots[(u64)blockIdx.x * 256 + w];
-    const u64 at0 = WRITE ? blk_off[blockIdx.x] + seg_pre : 0;
+    if (WRITE) for (int w = 0; w < wv; w++) seg_pre += cnt_slots[(u64)tile * 256 + w];
+    const u64 at0 = WRITE ? blk_off[tile] + seg_pre : 0;
     const u64 lt_mask = (1ull << lane) - 1ull;
     u32 wslots = 0, carry_o = 0, carry_P = 0;
     bool spill = false;
@@ -1513,14 +1516,14 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
                 const u32 e = s_val[WRITE ? 0 : tid], o = s_own[WRITE ? 0 : tid];
                 u32 pre = 0;
                 for (u32 w = 0; w < (o >> 12); w++) pre += s_seg[w];
-                staged[(u64)blockIdx.x * VT_QUOTA + pre + (o & 4095u)] = ((u64)(u32)s_key[e >> 16] << 32) | (u32)s_key[e & 0xFFFFu];
+                staged[(u64)tile * VT_QUOTA + pre + (o & 4095u)] = ((u64)(u32)s_key[e >> 16] << 32) | (u32)s_key[e & 0xFFFFu];
             }
-        } else if (tid < 4) cnt_slots[(u64)blockIdx.x * 256 + tid] = s_seg[tid];      // the WRITE pass does this tile again
+        } else if (tid < 4) cnt_slots[(u64)tile * 256 + tid] = s_seg[tid];      // the WRITE pass does this tile again
         if (tid == 0) {
-            blk_mode[blockIdx.x] = 1;
-            blk_slots[blockIdx.x] = total;
-            blk_staged[blockIdx.x] = keep_all ? 1 : 0;
-            blk_cand[blockIdx.x] = (u64)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            blk_mode[tile] = 1;
+            blk_slots[tile] = total;
+            blk_staged[tile] = keep_all ? 1 : 0;
+            blk_cand[tile] = (u64)s_w[0] + s_w[1] + s_w[2] + s_w[3];
         }
     }
 }
@@ -2287,37 +2290,84 @@ void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, con
     }
 }
 u64 verify_blocks(u64 n) { return (n + VT_TILE - 1) / VT_TILE; }
-template <bool WRITE>
-static void launch_candidates(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
-                              const u64 *blk_off, PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode)
+
+// The candidate passes that have something to do in FEW tiles get those tiles as a list instead of a grid over all tiles
+// (1.3e6 workgroups that look at a flag and leave cost 1.1-1.7 ms each, three such launches per seed).  which = 0: the tiles
+// the balanced kernel left to the walk; 1 / 2: the balanced kernel's / the walk's tiles whose slots the write pass has to
+// produce (some found, not all kept by the counting pass).  Order within the list does not matter: every tile writes to
+// places of its own.  *count must be zero.
+__global__ __launch_bounds__(256) void k_tile_list(u32 n_tiles, const u8 *__restrict__ blk_mode, const u32 *__restrict__ blk_slots,
+                                                   const u8 *__restrict__ blk_staged, int which, u32 *__restrict__ list, u32 *__restrict__ count)
 {
-    if (!n) return;
-    const dim3 g((unsigned)verify_blocks(n)), b(256);
-#define CAND_ARGS p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode
-    if (blk_mode) {                       // the balanced kernel takes the tiles it can do (and says which), the walk the others
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    bool want = false;
+    if (t < n_tiles) {
+        const bool walk = blk_mode[t] == 0;
+        if (which == 0) want = walk;
+        else want = (walk == (which == 2)) && blk_slots[t] != 0 && !blk_staged[t];
+    }
+    const u64 bal = __ballot(want);
+    if (!bal) return;
+    const int lane = threadIdx.x & 63;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(count, (u32)__popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (want) list[base + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = t;
+}
+void launch_tile_list(hipStream_t s, u64 n_tiles, const u8 *blk_mode, const u32 *blk_slots, const u8 *blk_staged, int which, u32 *list, u32 *count)
+{
+    if (n_tiles) hipLaunchKernelGGL(k_tile_list, grid_for(n_tiles), dim3(256), 0, s, (u32)n_tiles, blk_mode, blk_slots, blk_staged, which, list, count);
+}
+
+// pairs: the balanced kernel (k_candidates_pairs) or the walk (k_candidates); tiles / n_listed: the tiles to do (null: all)
+template <bool WRITE>
+static void launch_candidates(hipStream_t s, bool pairs, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                              const u64 *blk_off, PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode,
+                              const u32 *tiles, u32 n_listed)
+{
+    if (!n || (tiles && !n_listed)) return;
+    const dim3 g(tiles ? n_listed : (unsigned)verify_blocks(n)), b(256);
+#define CAND_ARGS p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles
+    if (pairs) {
         if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates_pairs<WRITE, true, true>), g, b, 0, s, CAND_ARGS);
         else if (sk_b) hipLaunchKernelGGL((k_candidates_pairs<WRITE, true, false>), g, b, 0, s, CAND_ARGS);
         else if (sk_c) hipLaunchKernelGGL((k_candidates_pairs<WRITE, false, true>), g, b, 0, s, CAND_ARGS);
         else hipLaunchKernelGGL((k_candidates_pairs<WRITE, false, false>), g, b, 0, s, CAND_ARGS);
+    } else {
+        if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates<WRITE, true, true>), g, b, 0, s, CAND_ARGS);
+        else if (sk_b) hipLaunchKernelGGL((k_candidates<WRITE, true, false>), g, b, 0, s, CAND_ARGS);
+        else if (sk_c) hipLaunchKernelGGL((k_candidates<WRITE, false, true>), g, b, 0, s, CAND_ARGS);
+        else hipLaunchKernelGGL((k_candidates<WRITE, false, false>), g, b, 0, s, CAND_ARGS);
     }
-    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates<WRITE, true, true>), g, b, 0, s, CAND_ARGS);
-    else if (sk_b) hipLaunchKernelGGL((k_candidates<WRITE, true, false>), g, b, 0, s, CAND_ARGS);
-    else if (sk_c) hipLaunchKernelGGL((k_candidates<WRITE, false, true>), g, b, 0, s, CAND_ARGS);
-    else hipLaunchKernelGGL((k_candidates<WRITE, false, false>), g, b, 0, s, CAND_ARGS);
 #undef CAND_ARGS
 }
 u64 verify_staging_elems(u64 n) { return verify_blocks(n) * VT_QUOTA; }
+// counting pass, all tiles: the balanced kernel (blk_mode != null; it says which tiles it left to the walk) or the walk
 void launch_candidates_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
                              const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode)
 {
-    launch_candidates<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged, blk_mode);
+    launch_candidates<false>(s, blk_mode != nullptr, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged, blk_mode,
+                             nullptr, 0);
 }
+// counting pass of the walk over the listed tiles (those the balanced kernel left)
+void launch_candidates_walk_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                                  const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode, const u32 *tiles, u32 n_listed)
+{
+    launch_candidates<false>(s, false, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged, blk_mode, tiles, n_listed);
+}
+// write pass: the kept slots of every tile, then the listed tiles of either kernel (blk_mode == null: the walk over all tiles)
 void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, const u64 *blk_off,
-                             PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode)
+                             PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode,
+                             const u32 *tiles_pairs, u32 n_pairs, const u32 *tiles_walk, u32 n_walk)
 {
     if (!n) return;
     hipLaunchKernelGGL(k_staged_slots, dim3((unsigned)verify_blocks(n)), dim3(VT_QUOTA), 0, s, staged, blk_slots, blk_staged, blk_off, slots);
-    launch_candidates<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode);
+    if (!blk_mode) {
+        launch_candidates<true>(s, false, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, nullptr, nullptr, 0);
+        return;
+    }
+    launch_candidates<true>(s, true, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles_pairs, n_pairs);
+    launch_candidates<true>(s, false, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles_walk, n_walk);
 }
 void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid)
 {

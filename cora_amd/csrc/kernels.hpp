@@ -111,9 +111,16 @@ u64 verify_staging_elems(u64 n);
 void launch_candidates_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
                              const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged,
                              u8 *blk_mode /* [blocks] which kernel did the tile; null: the walk (k_candidates) does them all */);
+// the walk's counting pass over the listed tiles (the ones the balanced kernel left: launch_tile_list, which 0)
+void launch_candidates_walk_count(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                                  const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode, const u32 *tiles, u32 n_listed);
+// tiles_pairs / tiles_walk: launch_tile_list which 1 / 2 (ignored when blk_mode is null: the walk then looks at every tile)
 void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots,
                              const u64 *blk_off /* scan of blk_slots */, PairRec *slots, const u64 *sk_b, const u32 *sk_c,
-                             u64 *staged, u8 *blk_staged, u8 *blk_mode);
+                             u64 *staged, u8 *blk_staged, u8 *blk_mode, const u32 *tiles_pairs, u32 n_pairs, const u32 *tiles_walk, u32 n_walk);
+// list[0 .. *count) = the tiles a candidate pass has to look at (which: 0 left to the walk, 1 / 2 write pass of the balanced kernel /
+// of the walk); *count (device) must be zero
+void launch_tile_list(hipStream_t s, u64 n_tiles, const u8 *blk_mode, const u32 *blk_slots, const u8 *blk_staged, int which, u32 *list, u32 *count);
 void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid /* [ceil(n_slots / 256)] */);
 void launch_slot_compact(hipStream_t s, const PairRec *slots, u64 n_slots, const u64 *blk_off, PairRec *pairs);
 void launch_sum_u64(hipStream_t s, const u64 *in, u64 n, u64 *out /* device, accumulated into */);

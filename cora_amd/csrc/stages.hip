@@ -270,6 +270,23 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         static const bool pairs_kernel = !(getenv("CORA_PAIRS") && atoi(getenv("CORA_PAIRS")) == 0);      // (0: the walk does every tile)
         if (pairs_kernel) RCQ(blk_mode.alloc(ab));
         launch_candidates_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p);
+        // the passes that have work in few tiles only take those tiles as lists: [0] the tiles left to the walk, [1] / [2] the
+        // tiles whose slots the write pass of the balanced kernel / of the walk must produce
+        DBuf<u32> tile_list[3], list_n;
+        u32 n_listed[3] = {0, 0, 0};
+        if (pairs_kernel) {
+            for (auto &l : tile_list) RCQ(l.alloc(ab));
+            RCQ(list_n.alloc(3));
+            HIPQ(hipMemsetAsync(list_n.p, 0, 3 * sizeof(u32), s));
+            launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 0, tile_list[0].p, list_n.p);
+            HIPQ(hipMemcpyAsync(n_listed, list_n.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+            HIPQ(hipStreamSynchronize(s));
+            launch_candidates_walk_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
+                                         tile_list[0].p, n_listed[0]);
+            launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 1, tile_list[1].p, list_n.p + 1);
+            launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 2, tile_list[2].p, list_n.p + 2);
+            HIPQ(hipMemcpyAsync(n_listed, list_n.p, sizeof n_listed, hipMemcpyDeviceToHost, s));
+        }
         if (exclusive_scan_u32_to_u64(s, blk_slots.p, slot_off.p, ab, scr_a.p, tots.p)) return fail(100, "scan launch failed");
         HIPQ(hipMemsetAsync(tots.p + 1, 0, sizeof(u64), s));
         launch_sum_u64(s, blk_cand.p, ab, tots.p + 1);
@@ -280,7 +297,8 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         if (sk_b || sk_c) job->stats.seed_sketch = 1;
         if (totals[0] == 0) { HIPQ(hipGetLastError()); return 0; }
         RCQ(slots.alloc(totals[0]));
-        launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p);
+        launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
+                                tile_list[1].p, n_listed[1], tile_list[2].p, n_listed[2]);
     }
     const u64 n_slots = totals[0], jb = (n_slots + 255) / 256;
     DBuf<u32> blk_valid;
