@@ -1631,23 +1631,51 @@ __global__ __launch_bounds__(256) void k_items_expand(DevParams p, const PairRec
     item_meta[2 * i + 1] = m2;
 }
 
-__global__ __launch_bounds__(256) void k_node_flags(const u64 *__restrict__ item_key, u64 m, u32 *__restrict__ head_flag,
+// List heads of the sorted items as a bit mask (bit l of word w = item 64 w + l opens the list of a new source position) and
+// the number of heads per word; scanned, that gives every word its first list, and with a popcount every item its list.
+// (Round 2 first kept a u32 flag and a u64 scanned list index per item: 6 GB written and read back at 5e8 items.)
+// 256 items per wave in four rounds, all loads in flight together.
+__global__ __launch_bounds__(256) void k_node_flags(const u64 *__restrict__ item_key, u64 m, u64 *__restrict__ head_mask, u32 *__restrict__ word_heads,
                                                     DevCounters *ctr)
 {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const u64 k = item_key[i];
-    const bool head = (i == 0) || (item_key[i - 1] >> 32) != (k >> 32);
-    head_flag[i] = head ? 1u : 0u;
-    if (i > 0 && item_key[i - 1] == k) ctr->n_dirty = 1;      // any tie: a flag, not a count
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 wbase = ((u64)blockIdx.x * 4 + wv) * 256;
+    if (wbase >= m) return;                                    // (wave-uniform)
+    u64 k[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u64 i = wbase + (u64)r * 64 + lane;
+        k[r] = i < m ? item_key[i] : 0ull;
+    }
+    u64 before = 0;
+    if (lane == 0 && wbase > 0) before = item_key[wbase - 1];
+    bool tie = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u64 i = wbase + (u64)r * 64 + lane;
+        u64 prev = __shfl_up(k[r], 1, 64);
+        const u64 tail = r ? __shfl(k[r ? r - 1 : 0], 63, 64) : before;
+        if (lane == 0) prev = tail;
+        const bool head = i < m && (i == 0 || (prev >> 32) != (k[r] >> 32));
+        tie = tie || (i < m && i > 0 && prev == k[r]);
+        const u64 bal = __ballot(head);
+        if (lane == 0 && wbase + (u64)r * 64 < m) { head_mask[(wbase >> 6) + r] = bal; word_heads[(wbase >> 6) + r] = (u32)__popcll(bal); }
+    }
+    if (tie) ctr->n_dirty = 1;                                 // any tie: a flag, not a count
 }
 
-__global__ __launch_bounds__(256) void k_node_starts(const u32 *__restrict__ head_flag, const u64 *__restrict__ node_of_excl, u64 m,
+// node_start[list] = its first item: one thread per mask word, word_first[w] = lists that open before word w
+__global__ __launch_bounds__(256) void k_node_starts(const u64 *__restrict__ head_mask, const u64 *__restrict__ word_first, u64 n_words,
                                                      u32 *__restrict__ node_start)
 {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    if (head_flag[i]) node_start[node_of_excl[i]] = (u32)i;
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    u64 bits = head_mask[w];
+    u64 at = word_first[w];
+    while (bits) {
+        node_start[at++] = (u32)(w * 64 + (u64)(__ffsll((long long)bits) - 1));
+        bits &= bits - 1;
+    }
 }
 
 __device__ __forceinline__ bool same_window(const DevParams &p, u64 a, u64 b)
@@ -1682,13 +1710,14 @@ __device__ __forceinline__ u32 find_item(const u64 *__restrict__ item_key, const
 // a surviving item's block length is the length of the chain it heads (k_chain_walk).  One search per item instead of
 // one per chain step.  Lists with tied targets are redone by the host in the reference's order.
 __global__ __launch_bounds__(256) void k_chain_link(DevParams p, const u64 *__restrict__ item_key, const u32 *__restrict__ item_meta,
-                                                    const u32 *__restrict__ head_flag, const u64 *__restrict__ node_of_excl,
+                                                    const u64 *__restrict__ head_mask, const u64 *__restrict__ word_first,
                                                     const u32 *__restrict__ node_start, u32 n_nodes, u64 m, u32 *__restrict__ succ,
                                                     int16_t *__restrict__ blen)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
-    const u32 nd = (u32)(node_of_excl[i] + head_flag[i] - 1);
+    // the item's list: lists opened before its mask word + heads of the word up to and including the item - 1
+    const u32 nd = (u32)(word_first[i >> 6] + (u64)__popcll(head_mask[i >> 6] & ((2ull << (i & 63)) - 1ull)) - 1ull);
     const u64 key = item_key[i];
     const u64 src = key >> 32, tgt = key & 0xFFFFFFFFull;
     const u32 meta = item_meta[i];
@@ -2387,20 +2416,20 @@ void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs
 {
     if (n_pairs) hipLaunchKernelGGL(k_items_expand, grid_for(n_pairs), dim3(256), 0, s, p, pairs, n_pairs, item_key, item_meta);
 }
-void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr)
+void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u64 *head_mask, u32 *word_heads, DevCounters *ctr)
 {
-    if (m) hipLaunchKernelGGL(k_node_flags, grid_for(m), dim3(256), 0, s, item_key, m, head_flag, ctr);
+    if (m) hipLaunchKernelGGL(k_node_flags, grid_for((m + 3) / 4), dim3(256), 0, s, item_key, m, head_mask, word_heads, ctr);      // 1024 items per block
 }
-void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start)
+void launch_node_starts(hipStream_t s, const u64 *head_mask, const u64 *word_first, u64 m, u32 *node_start)
 {
-    if (m) hipLaunchKernelGGL(k_node_starts, grid_for(m), dim3(256), 0, s, head_flag, node_of_excl, m, node_start);
+    if (m) hipLaunchKernelGGL(k_node_starts, grid_for((m + 63) / 64), dim3(256), 0, s, head_mask, word_first, (m + 63) / 64, node_start);
 }
-void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u32 *head_flag,
-                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen)
+void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u64 *head_mask,
+                  const u64 *word_first, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen)
 {
     if (!m) return;
     (void)hipMemsetAsync(blen, 0, m * sizeof(int16_t), s);
-    hipLaunchKernelGGL(k_chain_link, grid_for(m), dim3(256), 0, s, p, item_key, item_meta, head_flag, node_of_excl, node_start, n_nodes, m, succ, blen);
+    hipLaunchKernelGGL(k_chain_link, grid_for(m), dim3(256), 0, s, p, item_key, item_meta, head_mask, word_first, node_start, n_nodes, m, succ, blen);
     hipLaunchKernelGGL(k_chain_walk, grid_for(m), dim3(256), 0, s, succ, m, blen);
 }
 

@@ -125,10 +125,11 @@ void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slo
 void launch_slot_compact(hipStream_t s, const PairRec *slots, u64 n_slots, const u64 *blk_off, PairRec *pairs);
 void launch_sum_u64(hipStream_t s, const u64 *in, u64 n, u64 *out /* device, accumulated into */);
 void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs, u64 n_pairs, u64 *item_key, u32 *item_meta);
-void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u32 *head_flag, DevCounters *ctr);
-void launch_node_starts(hipStream_t s, const u32 *head_flag, const u64 *node_of_excl, u64 m, u32 *node_start);
-void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u32 *head_flag,
-                  const u64 *node_of_excl, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ /* [m] scratch */, int16_t *blen);
+// heads of the lists in the sorted items as a mask (bit l of word w = item 64 w + l) + heads per word; word_first = its exclusive scan
+void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u64 *head_mask /* [ceil(m/64)] */, u32 *word_heads /* [ceil(m/64)] */, DevCounters *ctr);
+void launch_node_starts(hipStream_t s, const u64 *head_mask, const u64 *word_first, u64 m, u32 *node_start);
+void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u64 *head_mask,
+                  const u64 *word_first, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen);
 
 void launch_exact_size(hipStream_t s, int cw, const u32 *cls_entries, const u8 *merge_prev, u32 n_cls, u32 *size, DevCounters *ctr);
 void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cls_entries, const u64 *ent_off, const u32 *ent, const u8 *ent_dir,

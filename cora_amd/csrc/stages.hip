@@ -355,22 +355,25 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         if (radix_sort(s, kk, kt, M, 0, gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
         if (radix_sort(s, kk, kt, M, 32, 32 + gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
         trace_mark(job, "items: two sorts", 2);
-        RCQ(hf.alloc(M)); RCQ(nexcl.alloc(M)); RCQ(scr.alloc(scan_scratch_elems(M))); RCQ(tot.alloc(1)); RCQ(blen.alloc(M));
+        const u64 item_words = (M + 63) / 64;               // list heads as a mask: one word per 64 items
+        DBuf<u64> head_mask;
+        RCQ(head_mask.alloc(item_words)); RCQ(hf.alloc(item_words)); RCQ(nexcl.alloc(item_words));
+        RCQ(scr.alloc(scan_scratch_elems(M))); RCQ(tot.alloc(1)); RCQ(blen.alloc(M));
         trace_mark(job, "items: flag buffers", 3);
         DevCounters h;
         ZERO_COUNTERS(job, n_dirty, 1);
-        launch_node_flags(s, kk.a, M, hf.p, job->ctr.p);
-        if (exclusive_scan_u32_to_u64(s, hf.p, nexcl.p, M, scr.p, tot.p)) return fail(100, "scan launch failed");
+        launch_node_flags(s, kk.a, M, head_mask.p, hf.p, job->ctr.p);                    // hf: heads per word, nexcl: lists before each word
+        if (exclusive_scan_u32_to_u64(s, hf.p, nexcl.p, item_words, scr.p, tot.p)) return fail(100, "scan launch failed");
         u64 n_nodes = 0;
         HIPQ(hipMemcpyAsync(&n_nodes, tot.p, sizeof n_nodes, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
         RCQ(nstart.alloc(n_nodes + 1));
-        launch_node_starts(s, hf.p, nexcl.p, M, nstart.p);
+        launch_node_starts(s, head_mask.p, nexcl.p, M, nstart.p);
         const u32 m32 = (u32)M;
         HIPQ(hipMemcpyAsync(nstart.p + n_nodes, &m32, sizeof(u32), hipMemcpyHostToDevice, s));
         DBuf<u32> succ;
         RCQ(succ.alloc(M));
-        launch_chain(s, dp, kk.a, kk.c, hf.p, nexcl.p, nstart.p, (u32)n_nodes, M, succ.p, blen.p);
+        launch_chain(s, dp, kk.a, kk.c, head_mask.p, nexcl.p, nstart.p, (u32)n_nodes, M, succ.p, blen.p);
         HIPQ(hipGetLastError());
         trace_mark(job, "items: lists + chains", 4);
         // ---- bytes: lists the device can order itself are written here; the others go to the host (kernels.hip) ----
