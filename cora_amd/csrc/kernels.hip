@@ -1733,10 +1733,32 @@ __global__ __launch_bounds__(256) void k_chain_link(DevParams p, const u64 *__re
     if (s != NO_ITEM) blen[s] = -1;
 }
 
-__global__ __launch_bounds__(256) void k_chain_walk(const u32 *__restrict__ succ, u64 m, int16_t *__restrict__ blen)
+// The items that survived (were absorbed by nobody) head a chain each; its length is their block length.  They are one item
+// in eight, so they are listed first (k_alive_mask + the mask kernels) and the walk runs one thread per listed item: with a
+// thread per item a wave held seven walkers and fifty-seven lanes that had left (7.9 ms at 5e8 items).
+__global__ __launch_bounds__(256) void k_alive_mask(const int16_t *__restrict__ blen, u64 m, u64 *__restrict__ mask)
 {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m || blen[i] == -1) return;                 // (blen was zeroed before k_chain_link; only absorbed items hold -1)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 wbase = ((u64)blockIdx.x * 4 + wv) * 256;      // 256 items per wave in four rounds, the loads in flight together
+    if (wbase >= m) return;
+    int16_t b[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u64 i = wbase + (u64)r * 64 + lane;
+        b[r] = i < m ? blen[i] : (int16_t)-1;                // (blen was zeroed before k_chain_link; only absorbed items hold -1)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u64 bal = __ballot(b[r] != -1);
+        if (lane == 0 && wbase + (u64)r * 64 < m) mask[(wbase >> 6) + r] = bal;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chain_walk(const u32 *__restrict__ succ, const u32 *__restrict__ alive, u64 n_alive, int16_t *__restrict__ blen)
+{
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_alive) return;
+    const u32 i = alive[t];
     u32 L = 1;
     for (u32 j = succ[i]; j != NO_ITEM; j = succ[j]) L++; // at most K steps: offset 1 shrinks by one per link
     blen[i] = (int16_t)L;
@@ -2424,13 +2446,20 @@ void launch_node_starts(hipStream_t s, const u64 *head_mask, const u64 *word_fir
 {
     if (m) hipLaunchKernelGGL(k_node_starts, grid_for((m + 63) / 64), dim3(256), 0, s, head_mask, word_first, (m + 63) / 64, node_start);
 }
-void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u64 *head_mask,
-                  const u64 *word_first, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen)
+void launch_chain_link(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u64 *head_mask,
+                       const u64 *word_first, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen)
 {
     if (!m) return;
     (void)hipMemsetAsync(blen, 0, m * sizeof(int16_t), s);
     hipLaunchKernelGGL(k_chain_link, grid_for(m), dim3(256), 0, s, p, item_key, item_meta, head_mask, word_first, node_start, n_nodes, m, succ, blen);
-    hipLaunchKernelGGL(k_chain_walk, grid_for(m), dim3(256), 0, s, succ, m, blen);
+}
+void launch_alive_mask(hipStream_t s, const int16_t *blen, u64 m, u64 *mask)
+{
+    if (m) hipLaunchKernelGGL(k_alive_mask, grid_for((m + 3) / 4), dim3(256), 0, s, blen, m, mask);
+}
+void launch_chain_walk(hipStream_t s, const u32 *succ, const u32 *alive, u64 n_alive, int16_t *blen)
+{
+    if (n_alive) hipLaunchKernelGGL(k_chain_walk, grid_for(n_alive), dim3(256), 0, s, succ, alive, n_alive, blen);
 }
 
 }  // namespace cora

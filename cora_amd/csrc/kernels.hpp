@@ -128,8 +128,12 @@ void launch_items_expand(hipStream_t s, const DevParams &p, const PairRec *pairs
 // heads of the lists in the sorted items as a mask (bit l of word w = item 64 w + l) + heads per word; word_first = its exclusive scan
 void launch_node_flags(hipStream_t s, const u64 *item_key, u64 m, u64 *head_mask /* [ceil(m/64)] */, u32 *word_heads /* [ceil(m/64)] */, DevCounters *ctr);
 void launch_node_starts(hipStream_t s, const u64 *head_mask, const u64 *word_first, u64 m, u32 *node_start);
-void launch_chain(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u64 *head_mask,
-                  const u64 *word_first, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen);
+// diagonal block merge as links: succ[i] = the item that continues item i's diagonal in the next position's list (absorbed: blen -1);
+// then the surviving items (launch_alive_mask + mask count / emit) walk their chains: blen = chain length
+void launch_chain_link(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *item_meta, const u64 *head_mask,
+                       const u64 *word_first, const u32 *node_start, u32 n_nodes, u64 m, u32 *succ, int16_t *blen);
+void launch_alive_mask(hipStream_t s, const int16_t *blen, u64 m, u64 *mask /* [ceil(m/64)] */);
+void launch_chain_walk(hipStream_t s, const u32 *succ, const u32 *alive, u64 n_alive, int16_t *blen);
 
 void launch_exact_size(hipStream_t s, int cw, const u32 *cls_entries, const u8 *merge_prev, u32 n_cls, u32 *size, DevCounters *ctr);
 void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cls_entries, const u64 *ent_off, const u32 *ent, const u8 *ent_dir,

@@ -373,7 +373,24 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         HIPQ(hipMemcpyAsync(nstart.p + n_nodes, &m32, sizeof(u32), hipMemcpyHostToDevice, s));
         DBuf<u32> succ;
         RCQ(succ.alloc(M));
-        launch_chain(s, dp, kk.a, kk.c, head_mask.p, nexcl.p, nstart.p, (u32)n_nodes, M, succ.p, blen.p);
+        launch_chain_link(s, dp, kk.a, kk.c, head_mask.p, nexcl.p, nstart.p, (u32)n_nodes, M, succ.p, blen.p);
+        {
+            // the surviving items, listed; each walks its chain (head_mask and hf / nexcl have served: reused for the list's mask and counts)
+            const u64 nb = (item_words + 255) / 256;
+            DBuf<u64> aoff;
+            DBuf<u32> acnt, alive;
+            RCQ(acnt.alloc(nb)); RCQ(aoff.alloc(nb));
+            launch_alive_mask(s, blen.p, M, head_mask.p);
+            launch_mask_count(s, head_mask.p, item_words, acnt.p);
+            if (exclusive_scan_u32_to_u64(s, acnt.p, aoff.p, nb, scr.p, tot.p)) return fail(100, "scan launch failed");
+            u64 n_alive = 0;
+            HIPQ(hipMemcpyAsync(&n_alive, tot.p, sizeof n_alive, hipMemcpyDeviceToHost, s));
+            HIPQ(hipStreamSynchronize(s));
+            RCQ(alive.alloc(n_alive));
+            launch_mask_emit(s, head_mask.p, item_words, aoff.p, alive.p);
+            launch_chain_walk(s, succ.p, alive.p, n_alive, blen.p);
+            HIPQ(hipStreamSynchronize(s));              // (alive lives on this frame)
+        }
         HIPQ(hipGetLastError());
         trace_mark(job, "items: lists + chains", 4);
         // ---- bytes: lists the device can order itself are written here; the others go to the host (kernels.hip) ----
