@@ -181,6 +181,20 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     job->sort_timing.enabled = true;
     const auto t_begin = std::chrono::steady_clock::now();
     double host_ms = 0;
+    if (!job->pool.arena && !job->arena_tried && job->genome_bases >= (256ull << 20)) {
+        // a large reference: the stage arrays are cut from one allocation (DevPool: why); 58 B per base hold what a d = 2
+        // build has in use at once (153 GB at 3.09 Gbp) with the 1 GB alignment of its big arrays, the rest comes from
+        // separate blocks as before.  CORA_ARENA=0: no arena; CORA_ARENA_GB=n: its size.
+        job->arena_tried = true;
+        size_t want = (size_t)dp.G * 58 + ((size_t)6 << 30), free_b = 0, total_b = 0;
+        if (getenv("CORA_ARENA_GB")) want = (size_t)atoll(getenv("CORA_ARENA_GB")) << 30;
+        const bool off = getenv("CORA_ARENA") && atoi(getenv("CORA_ARENA")) == 0;
+        if (!off && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)48 << 30)) {
+            if (want > free_b - ((size_t)16 << 30)) want = free_b - ((size_t)16 << 30);
+            const bool ok = job->pool.reserve_arena(want);
+            if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] arena of %.1f GB: %s\n", want / 1073741824.0, ok ? "reserved" : "not available, separate blocks");
+        }
+    }
     HIPQ(hipEventRecord(job->ev[0], s));
 
     // ---- stage 1: pack, hashed K-mer records (HTS:2499-2565) ----

@@ -43,9 +43,97 @@ struct DevPool {
     std::vector<Block> blocks;
     size_t n_malloc = 0, malloc_bytes = 0;               // since the pool was made (CORA_TRACE prints them per run)
     size_t live_bytes = 0, peak_live = 0;                // bytes handed out now / at most
+    // The arena (large references, single-GPU run): ONE allocation made before the first stage, from which the arrays
+    // are cut -- arrays of 256 MB and more at multiples of 1 GB from its low end, smaller ones at multiples of 2 MB from
+    // its high end.  The sort's scatter runs at the pace its buffers allow, and that differed by 15 % between arrays that
+    // came from separate hipMalloc calls (tools/sortbench, profiles/sort_alloc_size_sweep.sh: 19.9 ms per pass over 2.6e9
+    // two-word records in the first process on a box, 17.2-19.6 in later ones, the two directions of the ping-pong
+    // differently; shifting the arrays inside their allocations changed nothing) while arrays cut from one allocation
+    // at multiples of 1 GB ran at 17.1-17.6 ms in every process (at multiples of 2 MB: 17.0-18.6).  What the arena cannot
+    // hold comes from the blocks above, as before.
+    struct Range { size_t off, bytes; };
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<Range> arena_free;                       // by offset, coalesced
+    std::vector<Range> arena_live;
+    static constexpr size_t ARENA_BIG = (size_t)256 << 20, ARENA_ALIGN_BIG = (size_t)1 << 30, ARENA_ALIGN = (size_t)2 << 20;
+    bool reserve_arena(size_t bytes)
+    {
+        if (arena) return true;
+        bytes = (bytes + ARENA_ALIGN_BIG - 1) & ~(ARENA_ALIGN_BIG - 1);
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        arena = (char *)p; arena_bytes = bytes;
+        arena_free.assign(1, Range{0, bytes});
+        arena_live.clear();
+        n_malloc++; malloc_bytes += bytes;
+        return true;
+    }
+    void release_arena()                                 // (only when nothing of it is in use)
+    {
+        if (!arena || !arena_live.empty()) return;
+        (void)hipFree(arena);
+        arena = nullptr; arena_bytes = 0; arena_free.clear();
+    }
+    void *arena_get(size_t bytes)
+    {
+        const bool big = bytes >= ARENA_BIG;
+        const size_t al = big ? ARENA_ALIGN_BIG : ARENA_ALIGN;
+        const size_t base = (size_t)arena;               // (hipMalloc returns 2 MB-aligned addresses; 1 GB alignment is made here)
+        if (big) {
+            for (size_t i = 0; i < arena_free.size(); i++) {
+                const Range r = arena_free[i];
+                const size_t at = ((base + r.off + al - 1) & ~(al - 1)) - base;
+                if (at + bytes > r.off + r.bytes) continue;
+                arena_free.erase(arena_free.begin() + i);
+                if (at + bytes < r.off + r.bytes) arena_free.insert(arena_free.begin() + i, Range{at + bytes, r.off + r.bytes - (at + bytes)});
+                if (at > r.off) arena_free.insert(arena_free.begin() + i, Range{r.off, at - r.off});
+                arena_live.push_back(Range{at, bytes});
+                return arena + at;
+            }
+        } else {
+            for (size_t i = arena_free.size(); i-- > 0;) {
+                const Range r = arena_free[i];
+                if (r.bytes < bytes) continue;
+                const size_t at = ((base + r.off + r.bytes - bytes) & ~(al - 1)) - base;
+                if (at < r.off || at + bytes > r.off + r.bytes) continue;
+                arena_free.erase(arena_free.begin() + i);
+                if (at + bytes < r.off + r.bytes) arena_free.insert(arena_free.begin() + i, Range{at + bytes, r.off + r.bytes - (at + bytes)});
+                if (at > r.off) arena_free.insert(arena_free.begin() + i, Range{r.off, at - r.off});
+                arena_live.push_back(Range{at, bytes});
+                return arena + at;
+            }
+        }
+        return nullptr;
+    }
+    bool arena_put(void *p)
+    {
+        if (!arena || (char *)p < arena || (char *)p >= arena + arena_bytes) return false;
+        const size_t off = (size_t)((char *)p - arena);
+        for (size_t i = 0; i < arena_live.size(); i++) {
+            if (arena_live[i].off != off) continue;
+            Range r = arena_live[i];
+            arena_live[i] = arena_live.back(); arena_live.pop_back();
+            live_bytes -= r.bytes;
+            size_t k = 0;
+            while (k < arena_free.size() && arena_free[k].off < r.off) k++;
+            if (k > 0 && arena_free[k - 1].off + arena_free[k - 1].bytes == r.off) { k--; arena_free[k].bytes += r.bytes; }
+            else arena_free.insert(arena_free.begin() + k, r);
+            if (k + 1 < arena_free.size() && arena_free[k].off + arena_free[k].bytes == arena_free[k + 1].off) {
+                arena_free[k].bytes += arena_free[k + 1].bytes;
+                arena_free.erase(arena_free.begin() + k + 1);
+            }
+            return true;
+        }
+        return true;                                     // (inside the arena but not live: released twice; nothing to do)
+    }
     void *get(size_t bytes)
     {
-        bytes = (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
+        bytes = (bytes + (ARENA_ALIGN - 1)) & ~(ARENA_ALIGN - 1);
+        if (arena) {
+            void *q = arena_get(bytes);
+            if (q) { live_bytes += bytes; if (live_bytes > peak_live) peak_live = live_bytes; return q; }
+        }
         // smallest free block that holds the request.  A close fit (within 25 %) is the common case: the same sizes recur
         // in every run.  A LARGE request also takes a larger block rather than growing the pool: the stages of a
         // GRCh38-sized build ask for arrays of 12-47 GB each, and a pool that only ever adds blocks ended at 277 GB.
@@ -71,6 +159,7 @@ struct DevPool {
     }
     void put(void *p)
     {
+        if (arena_put(p)) return;
         for (auto &b : blocks) if (b.p == p) { if (!b.free) live_bytes -= b.bytes; b.free = true; return; }
     }
     void trim()
@@ -78,11 +167,14 @@ struct DevPool {
         std::vector<Block> keep;
         for (auto &b : blocks) { if (b.free) (void)hipFree(b.p); else keep.push_back(b); }
         blocks.swap(keep);
+        release_arena();
     }
     void destroy()
     {
         for (auto &b : blocks) (void)hipFree(b.p);
         blocks.clear();
+        if (arena) (void)hipFree(arena);
+        arena = nullptr; arena_bytes = 0; arena_free.clear(); arena_live.clear();
     }
 };
 inline thread_local DevPool *g_pool = nullptr;       // pool of the job the calling thread is working for
@@ -166,6 +258,7 @@ struct cora_hip_job {
     SortScratch sort_scratch;
     SortTiming sort_timing;
     DevPool pool;
+    bool arena_tried = false;           // cora_hip_job_run has asked for the pool's arena (large references)
     HBuf<u64> h_key, h_packed;
     HBuf<u32> h_meta, h_node_start;
     HBuf<u8> h_stream, h_exact;   // landing areas of the <Inexact> byte stream and of the <Exact> bytes

@@ -316,6 +316,9 @@ extern "C" int cora_hip_job_run_multi(cora_hip_job *job, int world, const int *d
 {
     if (!job || !job->have_ref) return fail(51, "no reference set");
     if (world < 1 || world > MAX_WORLD) return fail(19, "bad number of ranks %d (1..%d)", world, MAX_WORLD);
+    // the arena of an earlier single-GPU run of this job (DevPool) goes back: ranks may share this GPU and need its memory
+    job->pool.release_arena();
+    if (!job->pool.arena) job->arena_tried = false;
     int ndev = 0;
     HIPQ(hipGetDeviceCount(&ndev));
     std::vector<int> dev(world);

@@ -11,6 +11,7 @@
 // consecutive tiles to one XCD (see rs_scatter).  A single-pass variant with decoupled look-back was measured slower on
 // this chip; tools/sortbench.cpp compares with copy / read ceilings and with rocPRIM.
 #include "radix_sort.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace cora {
@@ -527,9 +528,12 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     }
     if (timed) {                                                   // read the events once, after the last pass
         RS_CHECK(hipEventSynchronize(scratch.ev[2 * pass - 1]));
+        static const bool trace = getenv("RS_TRACE") != nullptr;      // per-pass times and where the arrays lie
         for (int q = 0; q < pass; q++) {
             float ms = 0.f;
             RS_CHECK(hipEventElapsedTime(&ms, scratch.ev[2 * q], scratch.ev[2 * q + 1]));
+            if (trace) fprintf(stderr, "[rs] pass %d: scatter %.3f ms = %.0f GB/s  (result of the sort: a %p b %p c %p, spare: a %p b %p c %p)\n", q, ms,
+                               moved[q] / ms / 1e6, (void *)keys.a, (void *)keys.b, (void *)keys.c, (void *)tmp.a, (void *)tmp.b, (void *)tmp.c);
             timing->scatter_ms += ms;
             timing->scatter_launches += 1;
             timing->scatter_bytes += moved[q];
