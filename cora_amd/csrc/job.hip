@@ -197,6 +197,13 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     }
     HIPQ(hipEventRecord(job->ev[0], s));
 
+    // Which end of the arena the big arrays come from: the K-mer records and their sort take the high end, everything after them
+    // the low end.  Measured on two boxes, alternating (profiles/arena_end_ab.sh): exact stage 133.3 ms from the high end against
+    // 141.0 from the low end, seeds stage 424.3 against 422.0 -- pieces of device memory differ in how fast they take scattered
+    // writes ("Where the arrays lie"), and the 66 GB of the first sort fit the better part, the 95 GB of a seed's do not.
+    // CORA_ARENA_HIGH=0 / 1: the low / the high end throughout.
+    static const int arena_end = getenv("CORA_ARENA_HIGH") ? atoi(getenv("CORA_ARENA_HIGH")) : -1;
+    job->pool.big_from_high = arena_end != 0;
     // ---- stage 1: pack, hashed K-mer records (HTS:2499-2565) ----
     if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }   // (a run that failed half-way)
     RCQ(st_pack(job));
@@ -261,6 +268,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         RCQ(st_exact_finish(job, parts, fst, host_ms));
     }
 
+    job->pool.big_from_high = arena_end == 1;
     // ---- stage 3: per seed: codes, sort, equal runs, verification (HTS:2671-2800, 2138-2265) ----
     PairStore ps;
     {

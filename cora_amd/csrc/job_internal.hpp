@@ -75,33 +75,33 @@ struct DevPool {
         (void)hipFree(arena);
         arena = nullptr; arena_bytes = 0; arena_free.clear();
     }
+    bool big_from_high = false;                          // the big arrays come from the arena's high end, the small ones from its low end
+    void *carve(size_t i, size_t at, size_t bytes)       // [at, at + bytes) out of free range i
+    {
+        const Range r = arena_free[i];
+        arena_free.erase(arena_free.begin() + i);
+        if (at + bytes < r.off + r.bytes) arena_free.insert(arena_free.begin() + i, Range{at + bytes, r.off + r.bytes - (at + bytes)});
+        if (at > r.off) arena_free.insert(arena_free.begin() + i, Range{r.off, at - r.off});
+        arena_live.push_back(Range{at, bytes});
+        return arena + at;
+    }
     void *arena_get(size_t bytes)
     {
         const bool big = bytes >= ARENA_BIG;
         const size_t al = big ? ARENA_ALIGN_BIG : ARENA_ALIGN;
         const size_t base = (size_t)arena;               // (hipMalloc returns 2 MB-aligned addresses; 1 GB alignment is made here)
-        if (big) {
+        if (big != big_from_high) {                      // lowest place that fits
             for (size_t i = 0; i < arena_free.size(); i++) {
                 const Range r = arena_free[i];
                 const size_t at = ((base + r.off + al - 1) & ~(al - 1)) - base;
-                if (at + bytes > r.off + r.bytes) continue;
-                arena_free.erase(arena_free.begin() + i);
-                if (at + bytes < r.off + r.bytes) arena_free.insert(arena_free.begin() + i, Range{at + bytes, r.off + r.bytes - (at + bytes)});
-                if (at > r.off) arena_free.insert(arena_free.begin() + i, Range{r.off, at - r.off});
-                arena_live.push_back(Range{at, bytes});
-                return arena + at;
+                if (at + bytes <= r.off + r.bytes) return carve(i, at, bytes);
             }
-        } else {
+        } else {                                         // highest place that fits
             for (size_t i = arena_free.size(); i-- > 0;) {
                 const Range r = arena_free[i];
                 if (r.bytes < bytes) continue;
                 const size_t at = ((base + r.off + r.bytes - bytes) & ~(al - 1)) - base;
-                if (at < r.off || at + bytes > r.off + r.bytes) continue;
-                arena_free.erase(arena_free.begin() + i);
-                if (at + bytes < r.off + r.bytes) arena_free.insert(arena_free.begin() + i, Range{at + bytes, r.off + r.bytes - (at + bytes)});
-                if (at > r.off) arena_free.insert(arena_free.begin() + i, Range{r.off, at - r.off});
-                arena_live.push_back(Range{at, bytes});
-                return arena + at;
+                if (at >= r.off && at + bytes <= r.off + r.bytes) return carve(i, at, bytes);
             }
         }
         return nullptr;
