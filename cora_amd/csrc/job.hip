@@ -182,11 +182,11 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     const auto t_begin = std::chrono::steady_clock::now();
     double host_ms = 0;
     if (!job->pool.arena && !job->arena_tried && job->genome_bases >= (256ull << 20)) {
-        // a large reference: the stage arrays are cut from one allocation (DevPool: why); 58 B per base hold what a d = 2
-        // build has in use at once (153 GB at 3.09 Gbp) with the 1 GB alignment of its big arrays, the rest comes from
-        // separate blocks as before.  CORA_ARENA=0: no arena; CORA_ARENA_GB=n: its size.
+        // a large reference: the stage arrays are cut from one allocation (DevPool: why); 80 B per base hold what a d = 2
+        // build has in use at once (182 GB at 3.09 Gbp, the seed sorts' chain of five second-word arrays included) with the
+        // 1 GB alignment of its big arrays, the rest comes from separate blocks as before.  CORA_ARENA=0: no arena; CORA_ARENA_GB=n: its size.
         job->arena_tried = true;
-        size_t want = (size_t)dp.G * 58 + ((size_t)6 << 30), free_b = 0, total_b = 0;
+        size_t want = (size_t)dp.G * 80 + ((size_t)6 << 30), free_b = 0, total_b = 0;
         if (getenv("CORA_ARENA_GB")) want = (size_t)atoll(getenv("CORA_ARENA_GB")) << 30;
         const bool off = getenv("CORA_ARENA") && atoi(getenv("CORA_ARENA")) == 0;
         if (!off && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)48 << 30)) {
@@ -290,10 +290,19 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         // made: all seeds at once took 16 (d + 1) bytes per representative on top of the sort's spare buffers -- 242 GB
         // in use at once on a GRCh38-sized reference.  Without them every seed's codes come from one pass.
         const bool per_seed = use_sketch;
+        // The sketches' second word climbs through a chain of arrays during its sort (radix_sort.hip, "the second word
+        // climbs": seeds stage 424 -> 414 ms with 3 arrays, 407 ms with 5 at 2.6e9 representatives) when the arena has the
+        // room: 5 arrays want 70 B of arena per base, 3 want 56.  CORA_B_CHAIN=n: that many (1: a ping-pong, as without arena).
+        static const int b_chain_env = getenv("CORA_B_CHAIN") ? atoi(getenv("CORA_B_CHAIN")) : 0;
+        int b_chain = 1;
+        if (per_seed && job->pool.arena) {
+            b_chain = job->pool.arena_bytes >= (size_t)dp.G * 70 ? 5 : job->pool.arena_bytes >= (size_t)dp.G * 56 ? 3 : 1;
+            if (b_chain_env >= 1 && b_chain_env <= 5) b_chain = b_chain_env;
+        }
         auto make = [&](int q) -> int {
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
             cp[q] = codes[q].p; hp[q] = hists[q].p;
-            if (use_sketch && dp.nseeds >= 3) { RCQ(skb[q].alloc(NR)); sk.b[q] = skb[q].p; }
+            if (use_sketch && dp.nseeds >= 3) { RCQ(skb[q].alloc(NR * (u64)b_chain)); sk.b[q] = skb[q].p; }
             if (use_sketch && dp.nseeds != 3) { RCQ(skc[q].alloc(NR)); sk.c[q] = skc[q].p; }
             return 0;
         };
@@ -306,7 +315,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
                 RCQ(make(seed - 1));
                 launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, seed - 1);
             }
-            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, sk.b[seed - 1], sk.c[seed - 1]));
+            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, sk.b[seed - 1], sk.c[seed - 1], nullptr, b_chain));
             codes[seed - 1].release(); hists[seed - 1].release(); skb[seed - 1].release(); skc[seed - 1].release();
             cp[seed - 1] = nullptr; hp[seed - 1] = nullptr; sk.b[seed - 1] = nullptr; sk.c[seed - 1] = nullptr;
         }

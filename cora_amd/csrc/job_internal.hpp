@@ -364,7 +364,7 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
 int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBuf<u32> &reps, u64 &n_out);
 int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist = nullptr,
                    u64 *sk_b = nullptr, u32 *sk_c = nullptr /* [n] per-record sketches for the candidate kernels' pre-filter; sorted along */,
-                   const SortSource *from = nullptr);
+                   const SortSource *from = nullptr, int b_chain_n = 1 /* sk_b is the first of that many arrays of n words (radix_sort's chain) */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
 void multi_state_free(cora_hip_job *job);

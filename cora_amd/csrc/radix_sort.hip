@@ -499,6 +499,14 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);
     const u64 rec_bytes = 8 + (has_b ? 8 : 0) + (has_c ? 4 : 0);
     u64 moved[RS_MAX_PASSES];
+    // The second word climbs.  Measured at 2.6e9 two-word records, wherever the arrays lie (tools/sortbench <n> 1 gaps; RS_TRACE
+    // on the build): a pass that writes the second word ABOVE the array it reads it from takes 17.6-19.5 ms, one that writes it
+    // below 19.6-21.9 ms; where the first word goes makes no difference.  A ping-pong has one pass of each kind in turn.  With
+    // keys.b the first of a chain of arrays every pass writes into the next one up, and only the step back to the first goes down.
+    u64 *const chain = (has_b && !from && keys.b_chain_n > 1) ? keys.b : nullptr;
+    const int chain_n = chain ? keys.b_chain_n : 0;
+    const size_t chain_stride = keys.b_stride;
+    int chain_at = 0;
     for (int bit = bit_lo; bit < bit_hi; bit += 8, pass++) {
         const int nbits = (bit_hi - bit) < 8 ? (bit_hi - bit) : 8;
         const u32 mask = (1u << nbits) - 1u;
@@ -520,6 +528,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         if (pass == 0 && first_hist) th = first_hist;                    // the producer already counted this digit (tiles of radix_sort_tile_records())
         else launch_hist(s, has_c || has_b, tiles, word, n, shift, mask, th);
         launch_offsets(s, th, tiles, scratch);
+        if (chain) { chain_at = (chain_at + 1) % chain_n; tmp.b = chain + (size_t)chain_at * chain_stride; }
         if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass], s));
         launch_scatter_any(s, has_b, has_c, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
         if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass + 1], s));

@@ -16,6 +16,12 @@ struct SortArrays {
     u64 *a = nullptr;
     u64 *b = nullptr;
     u32 *c = nullptr;
+    // Optional (keys only): b is the first of b_chain_n arrays of b_stride words each, one behind the other in one allocation.
+    // Every pass then writes the second word into the NEXT array of that chain (back to the first after the last) instead of
+    // ping-ponging with tmp.b, which is not used: a pass whose second word goes to a higher address than it came from is the
+    // faster one (radix_sort.hip, "the second word climbs").
+    int b_chain_n = 0;
+    size_t b_stride = 0;
 };
 
 struct SortTiming {          // accumulated over calls; events are created lazily

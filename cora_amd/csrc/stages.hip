@@ -240,7 +240,8 @@ int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBu
 // (HTS:2671-2800, 2138-2265).  codes holds n records in which equal codes appear in increasing position.
 // sk_b / sk_c: the records' sketches (k_seed_codes_all), sorted along with them; either or both may be null.
 // from: as in st_exact_classes (the bit range is seed_sort_lo / _hi); codes / sk_b are then only sized for the n kept records.
-int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u64 *sk_b, u32 *sk_c, const SortSource *from)
+int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u64 *sk_b, u32 *sk_c, const SortSource *from,
+                   int b_chain_n)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
@@ -251,7 +252,8 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     DBuf<u32> skc_tmp;
     SortArrays ck, ct;
     ck.a = codes.p; ct.a = codes_tmp.p;
-    if (sk_b) { RCQ(skb_tmp.alloc(n)); ck.b = sk_b; ct.b = skb_tmp.p; }               // the sketches travel with their records
+    if (sk_b && b_chain_n > 1 && !from) { ck.b = sk_b; ck.b_chain_n = b_chain_n; ck.b_stride = (size_t)n; ct.b = sk_b + (size_t)n; }      // (ct.b: a place holder, the chain is used)
+    else if (sk_b) { RCQ(skb_tmp.alloc(n)); ck.b = sk_b; ct.b = skb_tmp.p; }               // the sketches travel with their records
     if (sk_c) { RCQ(skc_tmp.alloc(n)); ck.c = sk_c; ct.c = skc_tmp.p; }
     // the records are a (code << 32 | position); with a b array the sort's logical key is a:b, i.e. a's bits sit 64 higher
     const int key_lo = seed_sort_lo(sk_b != nullptr), key_hi = key_lo + 32;
