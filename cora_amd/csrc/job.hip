@@ -302,7 +302,11 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         auto make = [&](int q) -> int {
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
             cp[q] = codes[q].p; hp[q] = hists[q].p;
-            if (use_sketch && dp.nseeds >= 3) { RCQ(skb[q].alloc(NR * (u64)b_chain)); sk.b[q] = skb[q].p; }
+            if (use_sketch && dp.nseeds >= 3) {
+                if (b_chain > 1 && skb[q].alloc(NR * (u64)b_chain)) { b_chain = 1; (void)hipGetLastError(); }   // (no room for the chain: a ping-pong, from here on)
+                if (b_chain == 1) RCQ(skb[q].alloc(NR));
+                sk.b[q] = skb[q].p;
+            }
             if (use_sketch && dp.nseeds != 3) { RCQ(skc[q].alloc(NR)); sk.c[q] = skc[q].p; }
             return 0;
         };
