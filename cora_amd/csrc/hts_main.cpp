@@ -176,6 +176,8 @@ int main(int argc, char **argv)
     if (fai_len.empty()) { std::cout << "ERROR: empty .fai" << std::endl; return 52; }
 
     const double ms_parse = ms_since(t_start);
+    // one table pair per process: an arena that is quick to give back at exit (job.hip, CORA_ARENA_CAP_GB)
+    setenv("CORA_ARENA_CAP_GB", "190", 0);
     int rc = cora_hip_init(0);
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
     const double ms_init = ms_since(t_start);
@@ -256,6 +258,8 @@ int main(int argc, char **argv)
               << "  build(incl. tables to host) " << ms_build - ms_load << "  write_files " << ms_since(t_start) - ms_build
               << "  total " << ms_since(t_start) << std::endl;
     cora_hip_job_destroy(job);
+    if (getenv("CORA_TRACE")) std::cerr << "[cora] job destroyed at " << ms_since(t_start) << " ms" << std::endl;
     cora_hip_shutdown();
+    if (getenv("CORA_TRACE")) std::cerr << "[cora] shut down at " << ms_since(t_start) << " ms" << std::endl;
     return 0;
 }

@@ -187,6 +187,10 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         // 1 GB alignment of its big arrays, the rest comes from separate blocks as before.  CORA_ARENA=0: no arena; CORA_ARENA_GB=n: its size.
         job->arena_tried = true;
         size_t want = (size_t)dp.G * 80 + ((size_t)6 << 30), free_b = 0, total_b = 0;
+        // CORA_ARENA_CAP_GB: at most that much.  Giving back an arena that reaches into the last third of the device's memory
+        // is slow -- 16 ms for 190 GiB, 0.3 s for 210, 1.15 s for 236 (profiles/e2e_arena.py) -- which a job that builds
+        // many tables never notices and a process that builds one pays at its end: the executables cap theirs at 190 GiB.
+        if (getenv("CORA_ARENA_CAP_GB") && want > ((size_t)atoll(getenv("CORA_ARENA_CAP_GB")) << 30)) want = (size_t)atoll(getenv("CORA_ARENA_CAP_GB")) << 30;
         if (getenv("CORA_ARENA_GB")) want = (size_t)atoll(getenv("CORA_ARENA_GB")) << 30;
         const bool off = getenv("CORA_ARENA") && atoi(getenv("CORA_ARENA")) == 0;
         if (!off && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)48 << 30)) {
@@ -303,7 +307,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
             cp[q] = codes[q].p; hp[q] = hists[q].p;
             if (use_sketch && dp.nseeds >= 3) {
-                if (b_chain > 1 && skb[q].alloc(NR * (u64)b_chain)) { b_chain = 1; (void)hipGetLastError(); }   // (no room for the chain: a ping-pong, from here on)
+                // (no room for the chain: a shorter one, at last a ping-pong, from here on)
+                while (b_chain > 1 && skb[q].alloc(NR * (u64)b_chain)) { b_chain = b_chain > 3 ? 3 : 1; (void)hipGetLastError(); }
                 if (b_chain == 1) RCQ(skb[q].alloc(NR));
                 sk.b[q] = skb[q].p;
             }
