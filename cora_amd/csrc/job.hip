@@ -498,6 +498,30 @@ extern "C" int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint3
     return 0;
 }
 
+// The two-word sort with the second word climbing through a chain of `chain` arrays (SortArrays::b_chain_n, what the seed
+// sorts of a large build use), on host buffers.
+extern "C" int cora_hip_test_sort_chain_host(uint64_t *key_hi, uint64_t *key_lo, uint64_t n, int bit_lo, int bit_hi, int chain)
+{
+    if (g_device < 0) return fail(102, "cora_hip_init has not succeeded");
+    if (!key_hi || !key_lo || chain < 1 || chain > 8) return fail(19, "bad argument");
+    if (!n) return 0;
+    DBuf<u64> a, ta, b;
+    RCQ(a.alloc(n)); RCQ(ta.alloc(n)); RCQ(b.alloc(n * (u64)(chain > 1 ? chain : 2)));
+    HIPQ(hipMemcpy(a.p, key_hi, n * sizeof(u64), hipMemcpyHostToDevice));
+    HIPQ(hipMemcpy(b.p, key_lo, n * sizeof(u64), hipMemcpyHostToDevice));
+    SortArrays keys, tmp;
+    keys.a = a.p; keys.b = b.p; tmp.a = ta.p; tmp.b = b.p + n;
+    if (chain > 1) { keys.b_chain_n = chain; keys.b_stride = (size_t)n; }
+    SortScratch scratch;
+    const int rc = radix_sort(nullptr, keys, tmp, n, bit_lo, bit_hi, scratch, nullptr);
+    if (!rc) (void)hipDeviceSynchronize();
+    scratch.release();
+    if (rc) return fail(100, "radix sort failed (%d)", rc);
+    HIPQ(hipMemcpy(key_hi, keys.a, n * sizeof(u64), hipMemcpyDeviceToHost));
+    HIPQ(hipMemcpy(key_lo, keys.b, n * sizeof(u64), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // The sort whose first pass keeps one rank's records (radix_sort_count_kept + SortSource: the multi-GPU flow on few GPUs),
 // on host buffers: all n records in, the kept ones out, sorted.
 extern "C" int cora_hip_test_sort_kept_host(const uint64_t *key_hi, const uint64_t *key_lo, const uint32_t *val, uint64_t n, int bit_lo, int bit_hi,

@@ -21,7 +21,7 @@ BIN_DIR = os.path.join(_HERE, "bin")
 EXPORTS = [
     "cora_hip_init", "cora_hip_shutdown", "cora_hip_last_error", "cora_hip_job_create", "cora_hip_job_destroy",
     "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_run_multi", "cora_hip_device_count", "cora_hip_job_tables", "cora_hip_job_stats",
-    "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_sort_kept_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers", "cora_hip_test_window_bits",
+    "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_sort_chain_host", "cora_hip_test_sort_kept_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers", "cora_hip_test_window_bits",
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
     "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_seed_sketch", "cora_hip_shard_filter", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
     "cora_hip_tables_load", "cora_hip_tables_from_job", "cora_hip_tables_get_info", "cora_hip_tables_array_ptr",
@@ -128,6 +128,7 @@ def lib():
         L.cora_hip_radix_sort_noalloc.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_int, C.c_int]
         L.cora_hip_radix_sort_noalloc_max.restype = C.c_uint64
         L.cora_hip_test_sort_host.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_int, C.c_int]
+        L.cora_hip_test_sort_chain_host.argtypes = [C.c_void_p] * 2 + [C.c_uint64, C.c_int, C.c_int, C.c_int]
         L.cora_hip_test_sort_kept_host.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p]
         L.cora_hip_test_list_sort.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.cora_hip_test_pack.argtypes = [C.c_void_p] * 5
@@ -399,6 +400,11 @@ def sort_host(key_hi, key_lo=None, val=None, bit_lo=0, bit_hi=64):
     n = len(key_hi)
     _check(lib().cora_hip_test_sort_host(key_hi.ctypes.data, key_lo.ctypes.data if key_lo is not None else None,
                                          val.ctypes.data if val is not None else None, n, bit_lo, bit_hi))
+
+
+def sort_chain_host(key_hi, key_lo, bit_lo, bit_hi, chain):
+    """The two-word sort with the second word climbing through `chain` arrays (test helper); in place."""
+    _check(lib().cora_hip_test_sort_chain_host(key_hi.ctypes.data, key_lo.ctypes.data, len(key_hi), bit_lo, bit_hi, chain))
 
 
 def sort_kept_host(key_hi, key_lo, val, bit_lo, bit_hi, owner_mode, world, me):

@@ -388,6 +388,10 @@ uint64_t cora_hip_radix_sort_noalloc_max(void);
 
 /* Host-buffer convenience wrappers for tests: copy in, run the kernels, copy out. */
 int cora_hip_test_sort_host(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val, uint64_t n, int bit_lo, int bit_hi);
+/* The two-word sort as the seed sorts of a large build run it: the second word does not ping-pong between two arrays but
+ * climbs through `chain` arrays of one allocation, one per pass (1: the ping-pong).  Same result as cora_hip_test_sort_host.
+ * No counterpart in the reference (a property of this sort: radix_sort.hip, "the second word climbs"). */
+int cora_hip_test_sort_chain_host(uint64_t *key_hi, uint64_t *key_lo, uint64_t n, int bit_lo, int bit_hi, int chain);
 /* The same sort with the owner filter of the multi-GPU flow on few GPUs (cora_hip_shard_filter): of the n records only those
  * whose owner is `me` of `world` ranks are kept -- owner = top 32 bits of key_hi (owner_mode 1: as they are, hash ranges;
  * 2: multiplied by 0x9E3779B1 mod 2^32, seed codes) * world >> 32 -- in the first pass of the sort, which reads all

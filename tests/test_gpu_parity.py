@@ -45,6 +45,30 @@ def test_radix_sort_matches_numpy(n, shape):
         assert np.array_equal(val, order.astype(np.uint32))      # stable: ties keep input order
 
 
+@pytest.mark.parametrize("n", [1, 8191, 8192, 70001, 400_003])
+@pytest.mark.parametrize("chain,bits", [(1, (64, 128)), (2, (96, 128)), (3, (96, 128)), (5, (96, 128)), (5, (64, 128)), (3, (0, 128))])
+def test_radix_sort_with_the_second_word_in_a_chain(n, chain, bits):
+    """What the seed sorts of a large build do (SortArrays::b_chain_n): every pass writes the second word into the next of
+    `chain` arrays; 4, 8 and 16 passes, so the chain wraps around once, several times, or never."""
+    rs = np.random.RandomState(n % 997 + chain)
+    hi = rs.randint(0, 2 ** 62, size=n).astype(np.uint64) * np.uint64(3)
+    lo = rs.randint(0, 2 ** 62, size=n).astype(np.uint64)
+    if n > 100:
+        hi[rs.randint(0, n, size=n // 3)] = hi[0]
+        lo[rs.randint(0, n, size=n // 2)] = lo[1]
+    lo_bit, hi_bit = bits                           # bit 0 = LSB of lo, bit 64 = LSB of hi
+    if lo_bit >= 64:
+        key = (hi >> np.uint64(lo_bit - 64)) if hi_bit - lo_bit < 64 else hi
+        key = key & np.uint64((1 << (hi_bit - lo_bit)) - 1) if hi_bit - lo_bit < 64 else key
+        order = np.argsort(key, kind="stable")
+    else:
+        order = np.lexsort((lo, hi))                # all 128 bits; ties are whole-record ties
+    want_hi, want_lo = hi[order], lo[order]
+    hip.sort_chain_host(hi, lo, lo_bit, hi_bit, chain)
+    assert np.array_equal(hi, want_hi)
+    assert np.array_equal(lo, want_lo)
+
+
 def test_radix_sort_partial_bits():
     rs = np.random.RandomState(7)
     n = 50_000
