@@ -5,5 +5,5 @@ show() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms
 for i in 1 2; do
 echo "== default"; timeout -k 10 300 python bench.py --steps 3 --warmup 2 --no-extras 2> /dev/null | show
 echo "== low end"; CORA_ARENA_HIGH=0 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --no-extras 2> /dev/null | show
-echo "== high end"; CORA_ARENA_HIGH=1 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --no-extras 2> /dev/null | show
+echo "== high end"; CORA_ARENA_HIGH=1 RS_TRACE=1 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --no-extras 2> gpurun_out/end_high_$i.err | show
 done
