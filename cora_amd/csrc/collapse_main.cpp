@@ -69,7 +69,7 @@ int main(int argc, char **argv)
     const std::string frag = argv[13];
     const bool fragmented = frag != "NONE";
     const int frag_len = fragmented ? atoi(argv[14]) : 0;
-    if (fragmented && frag_len != 2 && frag_len != 4) { std::cout << "fragSignalLen can only be 2 or 4" << std::endl; return 6; }    // CL:557-561
+    if (fragmented && frag_len != 2 && frag_len != 4) { std::cout << "fragSignalLen can only be 2 or 4" << std::endl; return 19; }   // CL:557-561 (exit 19, CL:560)
     prm.read_len = atoi(argv[6]);
     const std::string split = argv[11];
     if (split == "FULL") prm.splits = 1; else if (split == "HALF") prm.splits = 2; else if (split == "THREEWAY") prm.splits = 3;

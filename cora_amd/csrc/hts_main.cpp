@@ -225,6 +225,13 @@ int main(int argc, char **argv)
             for (int r = 0; r < ranks; r++) devs[r] = r % n_gpus;
             std::cout << "Building on " << ranks << " ranks over " << (ranks < n_gpus ? ranks : n_gpus) << " GPU(s)" << std::endl;
             rc = cora_hip_job_run_multi(job, ranks, devs.data());
+            if (rc) {
+                // The peer-to-peer flow has only ever run with all ranks on ONE device: whatever stops it
+                // on a real multi-GPU node (peer access, memory, a link) must not fail `cora coraIndex` -- one GPU builds the
+                // same tables.  CORA_GPUS=1 skips the attempt.
+                std::cout << "WARNING: the build over " << ranks << " ranks failed (" << cora_hip_last_error() << "); falling back to one GPU" << std::endl;
+                rc = cora_hip_job_run(job);
+            }
         } else rc = cora_hip_job_run(job);
     }
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }

@@ -172,6 +172,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
 {
     if (!job || !job->have_ref) return fail(51, "no reference set");
     PoolScope pool_scope(&job->pool);
+    shard_state_free(job);                                 // (what a sharded run of this job left, e.g. one that failed half-way)
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
     cora_hip_stats &st = job->stats;
@@ -207,7 +208,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     // writes ("Where the arrays lie"), and the 66 GB of the first sort fit the better part, the 95 GB of a seed's do not.
     // CORA_ARENA_HIGH=0 / 1: the low / the high end throughout.
     static const int arena_end = getenv("CORA_ARENA_HIGH") ? atoi(getenv("CORA_ARENA_HIGH")) : -1;
-    job->pool.big_from_high = arena_end != 0;
+    job->pool.ranges.big_from_high = arena_end != 0;
     // ---- stage 1: pack, hashed K-mer records (HTS:2499-2565) ----
     if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }   // (a run that failed half-way)
     RCQ(st_pack(job));
@@ -272,7 +273,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         RCQ(st_exact_finish(job, parts, fst, host_ms));
     }
 
-    job->pool.big_from_high = arena_end == 1;
+    job->pool.ranges.big_from_high = arena_end == 1;
     // ---- stage 3: per seed: codes, sort, equal runs, verification (HTS:2671-2800, 2138-2265) ----
     PairStore ps;
     {
@@ -405,8 +406,8 @@ extern "C" int cora_hip_radix_sort(uint64_t *key_hi, uint64_t *key_lo, uint32_t 
     return 0;
 }
 
-// ---- the same sort for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
-// forbid hipMalloc).  No counterpart in the reference.  The per-tile digit histograms and the chunk sums/offsets, which
+// ---- the same sort for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc; not inside a stream
+// capture: it runs on the null stream and synchronises).  No counterpart in the reference.  The per-tile digit histograms and the chunk sums/offsets, which
 // cora_hip_radix_sort keeps in hipMalloc'ed SortScratch memory, live in a file-scope device array; every GPU holds its
 // own copy at its own address (looked up once per device).  Every call on a GPU shares that GPU's array: calls that
 // overlap on one GPU race.  Nothing in it needs to start at zero -- every pass writes each word before reading it.

@@ -2,6 +2,7 @@
 // job.hip (single-GPU orchestration) and shard.hip (multi-GPU stages).
 #pragma once
 #include "../../include/cora_hip.h"
+#include "arena_ranges.hpp"
 #include "finish.hpp"
 #include "kernels.hpp"
 #include "radix_sort.hpp"
@@ -51,85 +52,40 @@ struct DevPool {
     // differently; shifting the arrays inside their allocations changed nothing) while arrays cut from one allocation
     // at multiples of 1 GB ran at 17.1-17.6 ms in every process (at multiples of 2 MB: 17.0-18.6).  What the arena cannot
     // hold comes from the blocks above, as before.
-    struct Range { size_t off, bytes; };
     char *arena = nullptr;
     size_t arena_bytes = 0;
-    std::vector<Range> arena_free;                       // by offset, coalesced
-    std::vector<Range> arena_live;
-    static constexpr size_t ARENA_BIG = (size_t)256 << 20, ARENA_ALIGN_BIG = (size_t)1 << 30, ARENA_ALIGN = (size_t)2 << 20;
+    ArenaRanges ranges;                                  // which parts of the arena are free / handed out (arena_ranges.hpp)
     bool reserve_arena(size_t bytes)
     {
         if (arena) return true;
-        bytes = (bytes + ARENA_ALIGN_BIG - 1) & ~(ARENA_ALIGN_BIG - 1);
+        bytes = (bytes + ArenaRanges::ALIGN_BIG - 1) & ~(ArenaRanges::ALIGN_BIG - 1);
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
         arena = (char *)p; arena_bytes = bytes;
-        arena_free.assign(1, Range{0, bytes});
-        arena_live.clear();
+        ranges.reset((size_t)p, bytes);
         n_malloc++; malloc_bytes += bytes;
         return true;
     }
     void release_arena()                                 // (only when nothing of it is in use)
     {
-        if (!arena || !arena_live.empty()) return;
+        if (!arena || !ranges.live.empty()) return;
         (void)hipFree(arena);
-        arena = nullptr; arena_bytes = 0; arena_free.clear();
-    }
-    bool big_from_high = false;                          // the big arrays come from the arena's high end, the small ones from its low end
-    void *carve(size_t i, size_t at, size_t bytes)       // [at, at + bytes) out of free range i
-    {
-        const Range r = arena_free[i];
-        arena_free.erase(arena_free.begin() + i);
-        if (at + bytes < r.off + r.bytes) arena_free.insert(arena_free.begin() + i, Range{at + bytes, r.off + r.bytes - (at + bytes)});
-        if (at > r.off) arena_free.insert(arena_free.begin() + i, Range{r.off, at - r.off});
-        arena_live.push_back(Range{at, bytes});
-        return arena + at;
+        arena = nullptr; arena_bytes = 0; ranges.clear();
     }
     void *arena_get(size_t bytes)
     {
-        const bool big = bytes >= ARENA_BIG;
-        const size_t al = big ? ARENA_ALIGN_BIG : ARENA_ALIGN;
-        const size_t base = (size_t)arena;               // (hipMalloc returns 2 MB-aligned addresses; 1 GB alignment is made here)
-        if (big != big_from_high) {                      // lowest place that fits
-            for (size_t i = 0; i < arena_free.size(); i++) {
-                const Range r = arena_free[i];
-                const size_t at = ((base + r.off + al - 1) & ~(al - 1)) - base;
-                if (at + bytes <= r.off + r.bytes) return carve(i, at, bytes);
-            }
-        } else {                                         // highest place that fits
-            for (size_t i = arena_free.size(); i-- > 0;) {
-                const Range r = arena_free[i];
-                if (r.bytes < bytes) continue;
-                const size_t at = ((base + r.off + r.bytes - bytes) & ~(al - 1)) - base;
-                if (at >= r.off && at + bytes <= r.off + r.bytes) return carve(i, at, bytes);
-            }
-        }
-        return nullptr;
+        const size_t at = ranges.get(bytes);
+        return at == ArenaRanges::NONE ? nullptr : arena + at;
     }
     bool arena_put(void *p)
     {
         if (!arena || (char *)p < arena || (char *)p >= arena + arena_bytes) return false;
-        const size_t off = (size_t)((char *)p - arena);
-        for (size_t i = 0; i < arena_live.size(); i++) {
-            if (arena_live[i].off != off) continue;
-            Range r = arena_live[i];
-            arena_live[i] = arena_live.back(); arena_live.pop_back();
-            live_bytes -= r.bytes;
-            size_t k = 0;
-            while (k < arena_free.size() && arena_free[k].off < r.off) k++;
-            if (k > 0 && arena_free[k - 1].off + arena_free[k - 1].bytes == r.off) { k--; arena_free[k].bytes += r.bytes; }
-            else arena_free.insert(arena_free.begin() + k, r);
-            if (k + 1 < arena_free.size() && arena_free[k].off + arena_free[k].bytes == arena_free[k + 1].off) {
-                arena_free[k].bytes += arena_free[k + 1].bytes;
-                arena_free.erase(arena_free.begin() + k + 1);
-            }
-            return true;
-        }
-        return true;                                     // (inside the arena but not live: released twice; nothing to do)
+        live_bytes -= ranges.put((size_t)((char *)p - arena));      // (0: inside the arena but not live -- released twice; nothing to do)
+        return true;
     }
     void *get(size_t bytes)
     {
-        bytes = (bytes + (ARENA_ALIGN - 1)) & ~(ARENA_ALIGN - 1);
+        bytes = (bytes + (ArenaRanges::ALIGN - 1)) & ~(ArenaRanges::ALIGN - 1);
         if (arena) {
             void *q = arena_get(bytes);
             if (q) { live_bytes += bytes; if (live_bytes > peak_live) peak_live = live_bytes; return q; }
@@ -174,7 +130,7 @@ struct DevPool {
         for (auto &b : blocks) (void)hipFree(b.p);
         blocks.clear();
         if (arena) (void)hipFree(arena);
-        arena = nullptr; arena_bytes = 0; arena_free.clear(); arena_live.clear();
+        arena = nullptr; arena_bytes = 0; ranges.clear();
     }
 };
 inline thread_local DevPool *g_pool = nullptr;       // pool of the job the calling thread is working for

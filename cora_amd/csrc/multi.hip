@@ -140,6 +140,11 @@ struct Rank {
     bool all_to_all(int stage, int arg, const int *send_slots, const int *recv_slots, const uint32_t *elem_bytes, int n_slots)
     {
         TRY(cora_hip_shard_stage(job, stage, arg, t.pub[r].counts));
+        return exchange(send_slots, recv_slots, elem_bytes, n_slots);
+    }
+    // the all-to-all itself, after a stage has left its per-destination counts in t.pub[r].counts
+    bool exchange(const int *send_slots, const int *recv_slots, const uint32_t *elem_bytes, int n_slots)
+    {
         TRY(publish_slots(send_slots, n_slots));
         if (!sync()) return false;
         TRY(pull_all_to_all(recv_slots, elem_bytes, n_slots));
@@ -260,10 +265,15 @@ struct Rank {
         // (large references: the records' sketches travel with them -- every rank takes the same decision from the reference's size)
         static const int send_ab[2] = {CORA_SLOT_SEND_A, CORA_SLOT_SEND_B}, recv_ab[2] = {CORA_SLOT_RECV_A, CORA_SLOT_RECV_B};
         static const uint32_t eb_code2[2] = {8, 8};
-        const bool sketched = job->dp.nseeds >= 3 && (job->sketch_mode >= 0 ? job->sketch_mode != 0 : job->dp.G > (1ull << 28));
         for (int seed = 1; seed <= job->dp.nseeds; seed++) {
             if (filter) TRY(cora_hip_shard_stage(job, CORA_ST_SEED, seed, nullptr));
-            else if (!(sketched ? all_to_all(CORA_ST_SEED, seed, send_ab, recv_ab, eb_code2, 2) : all_to_all(CORA_ST_SEED, seed, send_a, recv_a, eb_code, 1))) return;
+            else {
+                // (the library decides whether the records carry sketches -- one rule, in shard.hip -- and says so after the stage)
+                TRY(cora_hip_shard_stage(job, CORA_ST_SEED, seed, t.pub[r].counts));
+                int sketched = 0;
+                TRY(cora_hip_shard_seed_sketch(job, &sketched));
+                if (!(sketched ? exchange(send_ab, recv_ab, eb_code2, 2) : exchange(send_a, recv_a, eb_code, 1))) return;
+            }
             mark("seed records");
             TRY(cora_hip_shard_stage(job, CORA_ST_VERIFY, seed, nullptr));
             mark("seed sort + verification");
@@ -330,44 +340,58 @@ extern "C" int cora_hip_job_run_multi(cora_hip_job *job, int world, const int *d
     // the other ranks' jobs: same parameters, the reference image copied from the caller's job (device to device)
     if (job->multi && (job->multi->devices != dev)) multi_state_free(job);
     if (!job->multi) {
+        // built aside and handed to the job only once every clone exists: a job must never keep a half-built team (a later call
+        // with the same devices would skip this block and run ranks on null clones -- round-2 advice)
         MultiState *m = new MultiState();
         m->devices = dev;
         m->clones.assign(world, nullptr);
-        job->multi = m;
+        struct Guard {                                         // every early return below destroys what exists so far
+            MultiState *m; int home;
+            ~Guard()
+            {
+                if (!m) return;
+                for (cora_hip_job *c : m->clones) if (c) { (void)hipSetDevice(c->device); cora_hip_job_destroy(c); }
+                (void)hipSetDevice(home);
+                delete m;
+            }
+        } guard{m, job->device};
         HIPQ(hipStreamSynchronize(job->stream));
         for (int r = 1; r < world; r++) {
             HIPQ(hipSetDevice(dev[r]));
             hipDeviceProp_t prop;
             HIPQ(hipGetDeviceProperties(&prop, dev[r]));
-            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { (void)hipSetDevice(job->device); return fail(102, "device %d is %s; the kernels are built for gfx950 only", dev[r], prop.gcnArchName); }
+            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(102, "device %d is %s; the kernels are built for gfx950 only", dev[r], prop.gcnArchName);
             if (dev[r] != job->device) {
                 int can = 0;
                 HIPQ(hipDeviceCanAccessPeer(&can, dev[r], job->device));
-                if (!can) { (void)hipSetDevice(job->device); return fail(102, "device %d cannot access device %d peer to peer", dev[r], job->device); }
+                if (!can) return fail(102, "device %d cannot access device %d peer to peer", dev[r], job->device);
                 for (int q = 0; q < world; q++) {
                     if (dev[q] == dev[r]) continue;
                     const hipError_t e = hipDeviceEnablePeerAccess(dev[q], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipSetDevice(job->device); return fail(100, "hipDeviceEnablePeerAccess(%d -> %d): %s", dev[r], dev[q], hipGetErrorString(e)); }
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(100, "hipDeviceEnablePeerAccess(%d -> %d): %s", dev[r], dev[q], hipGetErrorString(e));
                     (void)hipGetLastError();
                 }
             }
             cora_hip_job *c = nullptr;
             int rc = cora_hip_job_create(&job->prm, &c);
             if (!rc) {
+                m->clones[r] = c;                              // (the guard owns it from here)
                 c->sketch_mode = job->sketch_mode; c->hash_bits = job->hash_bits; c->host_threads = job->host_threads;
                 rc = set_reference_impl(c, job->ref_contigs.data(), (int32_t)job->ref_contigs.size(), job->ref_W, job->ref_image_bytes, nullptr, job->raw.p, nullptr);
             }
-            if (rc) { if (c) cora_hip_job_destroy(c); (void)hipSetDevice(job->device); return rc; }
-            m->clones[r] = c;
+            // CORA_TEST_FAIL_CLONE=r: tests make the set-up of rank r fail here, as a device without memory would
+            if (!rc && getenv("CORA_TEST_FAIL_CLONE") && atoi(getenv("CORA_TEST_FAIL_CLONE")) == r) rc = fail(101, "set-up of rank %d failed (CORA_TEST_FAIL_CLONE)", r);
+            if (rc) return rc;
         }
         HIPQ(hipSetDevice(job->device));
-        if (job->device != dev[0]) return fail(19, "internal: device mismatch");
         for (int q = 1; q < world; q++) {                     // the caller's device reads its peers as well
             if (dev[q] == job->device) continue;
             const hipError_t e = hipDeviceEnablePeerAccess(dev[q], 0);
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(100, "hipDeviceEnablePeerAccess(%d -> %d): %s", job->device, dev[q], hipGetErrorString(e));
             (void)hipGetLastError();
         }
+        guard.m = nullptr;                                    // complete: the job takes it
+        job->multi = m;
     }
     Team t;
     t.world = world;

@@ -236,15 +236,6 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
             cv[r] = (li < count) ? __builtin_nontemporal_load(c_in + base + li) : 0;
         }
     }
-    constexpr bool PRE_B = HAS_B && THREADS == 256;     // (512-thread tiles: the 32 registers would leave one workgroup per CU)
-    u64 ov[PRE_B ? RS_IPT : 1];             // so is the other key word
-    if (PRE_B) {
-#pragma unroll
-        for (int r = 0; r < RS_IPT; r++) {
-            u32 li = l0 + r * 64;
-            ov[r] = (li < count) ? __builtin_nontemporal_load(oth_in + base + li) : 0;
-        }
-    }
     for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0;
     __syncthreads();
 
@@ -302,11 +293,12 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
             stage[lpos[r]] = kw[r];
         }
     }
-    // 512-thread tiles fetch the other key word now: the key registers are free again, and the loads are in flight
-    // while the first word's runs are written (fetched only after that, every tile waited a whole memory latency there)
-    constexpr bool LATE_B = HAS_B && !PRE_B;
-    u64 lv[LATE_B ? RS_IPT : 1];
-    if (LATE_B) {
+    // The other key word is fetched now, not beside the digit word: two-word records go through 512-thread tiles, where 32
+    // more registers held from the start would leave one workgroup per CU (30.3 against 27.1 ms per pass at 2.9e9 records).
+    // Here the key registers are free again, and the loads are in flight while the first word's runs are written (fetched
+    // only after that, every tile waited a whole memory latency there).
+    u64 lv[HAS_B ? RS_IPT : 1];
+    if (HAS_B) {
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
@@ -329,7 +321,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
 #pragma unroll
         for (int r = 0; r < RS_IPT; r++) {
             u32 li = l0 + r * 64;
-            if (FILTER ? ((vmask >> r) & 1u) != 0 : li < count) stage[lpos[r]] = PRE_B ? ov[r] : lv[r];
+            if (FILTER ? ((vmask >> r) & 1u) != 0 : li < count) stage[lpos[r]] = lv[r];
         }
         __syncthreads();
 #pragma unroll
@@ -489,11 +481,12 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     int rc = scratch.reserve(from ? from->n : n);                  // (never shrinks: what radix_sort_count_kept left is still there)
     if (rc) return rc;
     if (timed && !scratch.ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) RS_CHECK(hipEventCreate(&scratch.ev[i]));
-    // records with a 4-byte payload go through 512-thread tiles of 8192 (their payload runs are twice as long: +9 % scatter
-    // bandwidth; tools/spreadwrite.cpp shows what short unaligned runs cost: 3.8 TB/s at 136 B, 4.6 at 264 B), all others
-    // through 256-thread tiles of 4096: two-word records need 140 VGPRs, which leaves 512-thread workgroups one per CU
-    // (measured at 2.9e9 records: 30.3 ms per pass against 27.1).  1024-thread tiles of 16384 (one workgroup per CU, runs
-    // twice as long) were slower still: 21.9 ms per pass against 20.4 at 2.6e9 two-word records
+    // records with a 4-byte payload or a second key word go through 512-thread tiles of 8192 (their output runs are twice as
+    // long: +9 % scatter bandwidth for 12-byte records, 27.1 -> 24.7 ms per pass for two-word records at 2.6e9;
+    // tools/spreadwrite.cpp shows what short unaligned runs cost: 3.8 TB/s at 136 B, 4.6 at 264 B), key-only records through
+    // 256-thread tiles of 4096.  The second key word is fetched late inside rs_scatter (see there) so that the 512-thread
+    // workgroups still fit two per CU.  1024-thread tiles of 16384 (one workgroup per CU, runs twice as long again) were
+    // slower: 21.9 ms per pass against 20.4 at 2.6e9 two-word records
     const bool has_b = keys.b != nullptr, has_c = keys.c != nullptr;
     const u32 tile_recs = radix_sort_tile_records(has_b, has_c);
     const u32 tiles = (u32)((n + tile_recs - 1) / tile_recs);

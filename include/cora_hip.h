@@ -143,8 +143,9 @@ int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t n_elems, v
 int cora_hip_shard_seed_sketch(cora_hip_job *job, int *on);
 /* How the K-mer and seed records reach their owner in this build (chosen by cora_hip_shard_begin: world <= 4, or
  * CORA_SHARD_FILTER=0/1).  *on = 0: the caller moves SEND_* to RECV_* by all-to-all after the KMERS and SEED stages.
- * *on = 1: every rank scanned ALL positions itself and kept the records it owns -- they are in RECV_* when the stage returns
- * and nothing is moved (a GPU pair shares one xGMI link: on 2 or 4 GPUs the all-to-all costs more than the extra scan).
+ * *on = 1: every rank scans ALL positions itself and nothing is moved after KMERS and SEED: the records of every position
+ * stay in SEND_* and the first pass of the following EXACT / VERIFY stage's sort reads them there and keeps the ones this rank
+ * owns (a GPU pair shares one xGMI link: on 2 or 4 GPUs the all-to-all costs more than the extra scan).
  * set >= 0 overrides the choice (before the KMERS stage; every rank the same).  No counterpart in the reference. */
 int cora_hip_shard_filter(cora_hip_job *job, int set, int *on);
 int cora_hip_shard_get_first_singleton(cora_hip_job *job, uint64_t *key);
@@ -374,8 +375,10 @@ int cora_hip_radix_sort(uint64_t *key_hi, uint64_t *key_lo, uint32_t *val,
                         uint64_t *tmp_hi, uint64_t *tmp_lo, uint32_t *tmp_val,
                         uint64_t n, int bit_lo, int bit_hi);
 
-/* cora_hip_radix_sort for callers that cannot allocate device memory: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments, same result (stable,
+/* cora_hip_radix_sort for callers that cannot allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc, code that runs between the launches of a captured graph.  (Not for use INSIDE a stream capture: like
+ * cora_hip_radix_sort it launches on the null stream and returns after hipStreamSynchronize, neither of which a capture
+ * allows.)  It has NO counterpart in the reference.  Same arguments, same result (stable,
  * sorted records back in the original arrays); the per-tile digit histograms that cora_hip_radix_sort keeps in
  * hipMalloc'ed memory live in a 4.1 MiB static device array instead, which every GPU the library runs on holds until
  * the process ends.  Limit: n <= cora_hip_radix_sort_noalloc_max() = 2^24 records; more is refused with status 19.

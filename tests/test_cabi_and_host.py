@@ -56,6 +56,30 @@ def test_executable_argument_errors_need_no_gpu(tmp_path):
     assert subprocess.run([exe] + args, stdout=subprocess.DEVNULL).returncode == 52                   # no .fai, HTS:171-179
 
 
+def test_collapse_argument_errors_need_no_gpu():
+    """Exit codes of the reference's argument checks that come before any device work (collapse.cpp:512-628)."""
+    _built()
+    exe = os.path.join(hip.BIN_DIR, "collapse")
+    assert subprocess.run([exe], stdout=subprocess.DEVNULL).returncode == 10                         # CL:512-533
+    args = ["list", "5", "out", "NOREF", "60", "100", "perfect", "x", "lrn", "SINGLE", "FULL", "GENERIC", "NONE", "0", "kill", "0"]
+    bad = list(args); bad[12] = "AAAA_TTTT_"; bad[13] = "3"
+    assert subprocess.run([exe] + bad, stdout=subprocess.DEVNULL).returncode == 19                   # signal length not 2 or 4: CL:557-561
+    bad = list(args); bad[10] = "QUARTER"
+    assert subprocess.run([exe] + bad, stdout=subprocess.DEVNULL).returncode == 9                    # CL:584-588
+    bad = list(args); bad[9] = "TRIPLE"
+    assert subprocess.run([exe] + bad, stdout=subprocess.DEVNULL).returncode == 8                    # CL:624-628
+
+
+def test_arena_range_bookkeeping_on_the_host(tmp_path):
+    """DevPool's arena ranges (csrc/arena_ranges.hpp) with made-up base addresses that are 2 MB- but not 1 GB-aligned: nothing is
+    handed out below or beyond the arena, everything is aligned on its absolute address, releases coalesce (round-2 advice)."""
+    exe = str(tmp_path / "arena_ranges_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "arena_ranges_test.cpp")])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:]
+
+
 def test_no_cpu_fallback_without_a_device():
     _built()
     import torch

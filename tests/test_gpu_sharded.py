@@ -116,6 +116,36 @@ def test_in_process_ranks_refuse_bad_devices():
     job.close()
 
 
+def test_a_failed_rank_setup_leaves_no_half_built_team(monkeypatch):
+    """Round-2 advice: when the set-up of some rank's clone fails, the job must not keep the team; the next call builds it afresh."""
+    hip.init(0)
+    c, want = helpers.golden_case("q_k50_d2")
+    job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]))
+    job.set_reference_file(helpers.input_path(c["input"]))
+    monkeypatch.setenv("CORA_TEST_FAIL_CLONE", "2")
+    with pytest.raises(hip.CoraHipError):
+        job.run_multi(3, [0, 0, 0])
+    monkeypatch.delenv("CORA_TEST_FAIL_CLONE")
+    job.run_multi(3, [0, 0, 0])                       # same device list: must not find (and run on) the clones of the failed call
+    e, en, i, inn = job.tables()
+    assert e == helpers.read(os.path.join(want, "Exact")) and i == helpers.read(os.path.join(want, "Inexact"))
+    job.close()
+
+
+def test_executable_falls_back_to_one_gpu_when_the_ranks_fail(tmp_path):
+    """The multi-GPU flow of the executable has never run on more than one real GPU: when it fails, homTable_setup says why and
+    builds on one GPU instead of failing `cora coraIndex` (round-2 advice)."""
+    c, want = helpers.golden_case("syn_k50_d2_p10t8")
+    exe = os.path.join(hip.BIN_DIR, "homTable_setup")
+    ex, inx = str(tmp_path / "E"), str(tmp_path / "I")
+    r = subprocess.run([exe, helpers.input_path(c["input"]), str(c["K"]), helpers.split_path("phys", c["p"]), ex, inx,
+                        helpers.split_path("par", c["t"]), "BOTH", str(c["d"]), "FULL"], env=dict(os.environ, CORA_RANKS="3", CORA_TEST_FAIL_CLONE="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "falling back to one GPU" in r.stdout and "CORA_TEST_FAIL_CLONE" in r.stdout
+    assert helpers.read(ex) == helpers.read(os.path.join(want, "Exact")) and helpers.read(inx) == helpers.read(os.path.join(want, "Inexact"))
+
+
 @pytest.mark.parametrize("ranks", [2, 5])
 def test_executable_builds_with_several_ranks(ranks, tmp_path):
     """CORA_RANKS forces the executable's multi-GPU flow (it would pick it by itself for a reference above 256 Mbp on a

@@ -46,8 +46,20 @@ def test_noalloc_sort_equals_the_allocating_one(shape):
             assert (w is None) == (g is None)
             if w is not None:
                 assert np.array_equal(w, g)
-        if shape == "key" and bit_lo == 0:                                   # and both are the sorted input
-            assert np.array_equal(got[0], np.sort(hi))
+        # ... and both are what numpy says: a stable sort on the chosen key bits (the allocating entry point shares the kernels,
+        # so equality with it alone would not show a fault they have in common)
+        def field(a, lo_bit, hi_bit):
+            w = hi_bit - lo_bit
+            return (a >> np.uint64(lo_bit)) & np.uint64((1 << w) - 1 if w < 64 else 0xFFFFFFFFFFFFFFFF)
+        if lo is None:
+            order = np.argsort(field(hi, bit_lo, bit_hi), kind="stable")
+        else:                                                                # logical key hi:lo, bits [bit_lo, 64 + bit_hi): bit_lo lies in lo
+            order = np.lexsort((field(lo, bit_lo, 64), field(hi, 0, bit_hi)))   # (lexsort is stable; last key is the primary one)
+        assert np.array_equal(got[0], hi[order])
+        if lo is not None:
+            assert np.array_equal(got[1], lo[order])
+        if val is not None:
+            assert np.array_equal(got[2], val[order])
 
 
 def test_noalloc_sort_refuses_inputs_above_its_maximum():
