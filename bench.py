@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip table_check, e2e, cpu_baseline and the secondary configuration")
     ap.add_argument("--collapse-reads", type=int, default=4_000_000, help="reads of the read-side figures of the secondary block (0 = skip)")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded", help="what N>1 ranks do (see the module text)")
+    ap.add_argument("--allow-replicas", action="store_true", help="N>1: if the sharded flow fails, measure N independent replicas instead of leaving with an error")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = host-staged rehearsal, several ranks may share a GPU)")
     ap.add_argument("--tmp", default=os.environ.get("CORA_TMP", tempfile.gettempdir()))
     a = ap.parse_args()
@@ -224,8 +225,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Warm-up.  The sharded flow over RCCL can only be rehearsed with one rank per GPU, i.e. not on a one-GPU box: if a rank
-    # fails in it, all ranks agree (over gloo) to measure independent replicas instead, and the line says so.
+    # Warm-up.  The sharded flow over RCCL can only be rehearsed with one rank per GPU, i.e. not on a one-GPU box.  If a rank fails
+    # in it, all ranks agree (over gloo) and LEAVE with status 3 and the cause on stderr: a replica figure would answer no question
+    # about the sharded build.  --allow-replicas: measure independent replicas instead, and the line says so.
     fallback = None
     try:
         if sharded and os.environ.get("CORA_BENCH_FAIL_SHARDED"):      # rehearsal of the fall-back itself
@@ -245,6 +247,13 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=side)
         if int(flag.item()):
             fallback = fallback or "another rank failed in the sharded flow"
+            if not a.allow_replicas:
+                print("[bench] rank %d: sharded flow failed (%s); no figure (--allow-replicas would measure replicas instead)" % (rank, fallback),
+                      file=sys.stderr, flush=True)
+                job.close()
+                dist.barrier(group=side)
+                dist.destroy_process_group()
+                sys.exit(3)
             print("[bench] rank %d: sharded flow failed (%s); measuring replicas" % (rank, fallback), file=sys.stderr, flush=True)
             sharded = False
             job.close()
@@ -265,6 +274,16 @@ def main():
         kmers_all = float(kt.item())
     else:
         kmers_all = float(st["kmers"])
+    # what every rank spent where in its last step, and what it sent to other ranks: a bad scaling curve can be read from the line
+    rank_reports = None
+    if world > 1:
+        mine = {"rank": rank, "device": local_rank, "kmers_owned": int(st["kmers"]), "representatives_owned": int(st["representatives"]),
+                "library_stage_ms": {k: round(st[k], 3) for k in ("ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total")},
+                "rs_scatter_ms": round(st["ms_sort_scatter"], 3)}
+        if sharded and sj.report:
+            mine.update({"kept_own": sj.report["kept_own"], "flow_ms": sj.report["ms"], "sent_bytes": sj.report["sent_bytes"]})
+        rank_reports = [None] * world if rank == 0 else None
+        dist.gather_object(mine, rank_reports, dst=0, group=side)
 
     if rank == 0:
         achieved = (sc_bytes / 1e9) / (sc_ms / 1e3) if sc_ms > 0 else 0.0
@@ -287,17 +306,23 @@ def main():
                                    % (tag, total_bases, len(names), " (GRCh38 primary-assembly lengths, 5 % N in >= 10 kbp runs, 45 % of bases from "
                                       "capped repeat families: synth.workload_grch38_like)" if a.workload == "grch38_like" else "", K, d,
                                       "rank 0's " if world > 1 else ""),
-                       "kmers": int(kmers_all), "kmers_rank0": int(st["kmers"]), "hom_pairs": int(st["hom_pairs"]),
+                       "kmers": int(kmers_all), "kmers_rank0": int(st["kmers"]), "representatives_rank0": int(st["representatives"]),
+                       "hom_pairs": int(st["hom_pairs"]),
                        "candidate_pairs": int(st["candidate_pairs"]), "inexact_nodes": int(st["inexact_nodes"]),
                        "exact_nodes": int(st["exact_nodes"]), "hash_mixed_runs": int(st["hash_mixed_runs"]),
                        "full_key_fallback": int(st["full_key_fallback"]), "dirty_nodes": int(st["dirty_nodes"]), "big_nodes": int(st["big_nodes"]),
-                       "parallelism": par_txt, "world_size": world, "sharded_flow_failure": fallback, "generate_s": round(t_gen, 1)},
+                       "parallelism": par_txt, "world_size": world, "sharded_flow_failure": fallback, "generate_s": round(t_gen, 1),
+                       "kept_own": bool(sharded and sj.kept_own),
+                       "arena": "stage arrays cut from one allocation of at most %s GiB per GPU (library default 190, CORA_ARENA_CAP_GB; the executable of `e2e` "
+                                "runs the same layout)" % os.environ.get("CORA_ARENA_CAP_GB", "190")},
             "stage_ms": {k: round(st[k], 3) for k in ("ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total")},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter (LSD radix scatter, all sorts of the path)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "launches_per_step": sc_n // max(1, a.steps), "avg_launch_ms": sc_ms / max(1, sc_n),
                          "algorithmic_bytes_per_launch": sc_bytes / max(1, sc_n), "traffic": traffic, "traffic_source": traffic_src},
         }
+        if rank_reports is not None:
+            out["ranks"] = rank_reports
         extras = world == 1 and not a.no_extras
         if extras:
             out.update(extras_after_timing(a, job, image, geom, names, W, K, d, phys, par, tmp, tag, st, e2e))

@@ -176,8 +176,6 @@ int main(int argc, char **argv)
     if (fai_len.empty()) { std::cout << "ERROR: empty .fai" << std::endl; return 52; }
 
     const double ms_parse = ms_since(t_start);
-    // one table pair per process: an arena that is quick to give back at exit (job.hip, CORA_ARENA_CAP_GB)
-    setenv("CORA_ARENA_CAP_GB", "190", 0);
     int rc = cora_hip_init(0);
     if (rc) { std::cout << "ERROR: " << cora_hip_last_error() << std::endl; return rc; }
     const double ms_init = ms_since(t_start);

@@ -168,6 +168,38 @@ int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_
     return 0;
 }
 
+// A large reference: the stage arrays are cut from one allocation (DevPool: why).  One GPU: 80 B per base hold what a d = 2
+// build has in use at once (182 GB at 3.09 Gbp, the seed sorts' chain of five second-word arrays included) with the 1 GB
+// alignment of its big arrays; the rest comes from separate blocks as before.  A rank of a sharded build holds 1 / world of the
+// records (80 B per base / world) and, when every rank scans all positions and keeps its own (keep_own: 2 to 4 GPUs), the
+// records of ALL positions of one stage while its sort's first pass reads them (16 B per base for a seed with sketches).
+// CORA_ARENA=0: no arena; CORA_ARENA_GB=n: its size.
+void reserve_job_arena(cora_hip_job *job, int world, bool keep_own)
+{
+    if (job->pool.arena || job->arena_tried || job->genome_bases < (256ull << 20)) return;
+    job->arena_tried = true;
+    const DevParams &dp = job->dp;
+    size_t want = (size_t)dp.G * 80 / (size_t)world + (keep_own ? (size_t)dp.G * 20 : 0) + ((size_t)6 << 30), free_b = 0, total_b = 0;
+    // At most 190 GiB (CORA_ARENA_CAP_GB=n: n).  Giving back an arena that reaches into the last third of the device's memory
+    // is slow -- 16 ms for 190 GiB, 0.3 s for 210, 1.15 s for 236 (profiles/e2e_arena.py) -- which a job that builds many
+    // tables never notices and a process that builds one pays at its end.  Round 2 capped the executables only and let
+    // in-process jobs take 236 GiB (seeds stage 407 instead of 414 ms: a chain of five arrays instead of three); now every
+    // build has the one layout, so that the benchmark's step and the executable's build are the same build.
+    const size_t cap = (size_t)(getenv("CORA_ARENA_CAP_GB") ? atoll(getenv("CORA_ARENA_CAP_GB")) : 190) << 30;
+    if (want > cap) want = cap;
+    if (getenv("CORA_ARENA_GB")) want = (size_t)atoll(getenv("CORA_ARENA_GB")) << 30;
+    if (getenv("CORA_ARENA") && atoi(getenv("CORA_ARENA")) == 0) return;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b <= ((size_t)48 << 30)) return;
+    // ranks that share the device (rehearsals) share what is free; each leaves room for the others and for what no arena holds
+    const size_t share = (size_t)(job->ranks_on_device > 0 ? job->ranks_on_device : 1);
+    const size_t room = share > 1 ? (total_b - ((size_t)24 << 30)) / share - ((size_t)6 << 30) : free_b - ((size_t)16 << 30);
+    if (share > 1 && (room > free_b || room < ((size_t)8 << 30))) return;
+    if (want > room) want = room;
+    const bool ok = job->pool.reserve_arena(want);
+    if (ok) job->arena_world = world;
+    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] arena of %.1f GB (%d rank(s)): %s\n", want / 1073741824.0, world, ok ? "reserved" : "not available, separate blocks");
+}
+
 extern "C" int cora_hip_job_run(cora_hip_job *job)
 {
     if (!job || !job->have_ref) return fail(51, "no reference set");
@@ -182,24 +214,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     job->sort_timing.enabled = true;
     const auto t_begin = std::chrono::steady_clock::now();
     double host_ms = 0;
-    if (!job->pool.arena && !job->arena_tried && job->genome_bases >= (256ull << 20)) {
-        // a large reference: the stage arrays are cut from one allocation (DevPool: why); 80 B per base hold what a d = 2
-        // build has in use at once (182 GB at 3.09 Gbp, the seed sorts' chain of five second-word arrays included) with the
-        // 1 GB alignment of its big arrays, the rest comes from separate blocks as before.  CORA_ARENA=0: no arena; CORA_ARENA_GB=n: its size.
-        job->arena_tried = true;
-        size_t want = (size_t)dp.G * 80 + ((size_t)6 << 30), free_b = 0, total_b = 0;
-        // CORA_ARENA_CAP_GB: at most that much.  Giving back an arena that reaches into the last third of the device's memory
-        // is slow -- 16 ms for 190 GiB, 0.3 s for 210, 1.15 s for 236 (profiles/e2e_arena.py) -- which a job that builds
-        // many tables never notices and a process that builds one pays at its end: the executables cap theirs at 190 GiB.
-        if (getenv("CORA_ARENA_CAP_GB") && want > ((size_t)atoll(getenv("CORA_ARENA_CAP_GB")) << 30)) want = (size_t)atoll(getenv("CORA_ARENA_CAP_GB")) << 30;
-        if (getenv("CORA_ARENA_GB")) want = (size_t)atoll(getenv("CORA_ARENA_GB")) << 30;
-        const bool off = getenv("CORA_ARENA") && atoi(getenv("CORA_ARENA")) == 0;
-        if (!off && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)48 << 30)) {
-            if (want > free_b - ((size_t)16 << 30)) want = free_b - ((size_t)16 << 30);
-            const bool ok = job->pool.reserve_arena(want);
-            if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] arena of %.1f GB: %s\n", want / 1073741824.0, ok ? "reserved" : "not available, separate blocks");
-        }
-    }
+    reserve_job_arena(job, 1, false);
     HIPQ(hipEventRecord(job->ev[0], s));
 
     // Which end of the arena the big arrays come from: the K-mer records and their sort take the high end, everything after them
@@ -359,6 +374,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     st.ms_sort_scatter = job->sort_timing.scatter_ms;
     st.n_sort_scatter = job->sort_timing.scatter_launches;
     st.sort_scatter_bytes = job->sort_timing.scatter_bytes;
+    st.pool_peak_bytes = job->pool.peak_live;
     if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] run %.3f ms; device pool: %zu blocks, %zu hipMalloc calls so far (%.1f MB), most in use at once %.1f MB\n",
                                       st.ms_total, job->pool.blocks.size(), job->pool.n_malloc, job->pool.malloc_bytes / 1e6, job->pool.peak_live / 1e6);
     return 0;

@@ -214,7 +214,8 @@ struct cora_hip_job {
     SortScratch sort_scratch;
     SortTiming sort_timing;
     DevPool pool;
-    bool arena_tried = false;           // cora_hip_job_run has asked for the pool's arena (large references)
+    bool arena_tried = false;           // the job has asked for the pool's arena (large references: reserve_job_arena)
+    int arena_world = 0;                // ... for a build over that many ranks (1: the single-GPU run)
     HBuf<u64> h_key, h_packed;
     HBuf<u32> h_meta, h_node_start;
     HBuf<u8> h_stream, h_exact;   // landing areas of the <Inexact> byte stream and of the <Exact> bytes
@@ -224,6 +225,7 @@ struct cora_hip_job {
     struct ShardState *shard = nullptr;   // multi-GPU stage state (shard.hip)
     struct MultiState *multi = nullptr;   // the other ranks' jobs of an in-process multi-GPU run (multi.hip)
     int device = 0;                       // HIP device the job's memory and stream live on
+    int ranks_on_device = 1;              // ranks of a sharded build that share this job's device (rehearsals on one GPU: they share its memory)
     std::vector<cora_hip_contig> ref_contigs;   // what set_reference_impl was given (a multi-GPU run replicates the reference)
     u32 ref_W = 0;
     size_t ref_image_bytes = 0;
@@ -323,6 +325,11 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
                    const SortSource *from = nullptr, int b_chain_n = 1 /* sk_b is the first of that many arrays of n words (radix_sort's chain) */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
+// in-process ranks (multi.hip): FINISH leaves this rank's <Inexact> bytes in its host buffer only -- the ranks share the address
+// space, so they are copied host to host into rank 0's table instead of going through the device (SLOT_F2 stays empty)
+void shard_set_host_gather(cora_hip_job *job, bool on);
+// the arena of a large build (DevPool): reserved once per job, sized for what `world` ranks leave each of them to hold
+void reserve_job_arena(cora_hip_job *job, int world, bool keep_own);
 void multi_state_free(cora_hip_job *job);
 int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_t n_contigs, u32 W, size_t image_bytes,
                        const uint8_t *host_image, const uint8_t *dev_image, DBuf<u8> *adopt);

@@ -496,7 +496,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     // on the build): a pass that writes the second word ABOVE the array it reads it from takes 17.6-19.5 ms, one that writes it
     // below 19.6-21.9 ms; where the first word goes makes no difference.  A ping-pong has one pass of each kind in turn.  With
     // keys.b the first of a chain of arrays every pass writes into the next one up, and only the step back to the first goes down.
-    u64 *const chain = (has_b && !from && keys.b_chain_n > 1) ? keys.b : nullptr;
+    u64 *const chain = (has_b && keys.b_chain_n > 1) ? keys.b : nullptr;
     const int chain_n = chain ? keys.b_chain_n : 0;
     const size_t chain_stride = keys.b_stride;
     int chain_at = 0;
@@ -511,6 +511,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
             // the kept records' offsets are in scratch.tile_hist already (radix_sort_count_kept, same bit range); the pass reads
             // the whole source and writes this rank's records, so what follows works on n records
             const u32 tiles0 = (u32)((from->n + tile_recs - 1) / tile_recs);
+            if (chain) { chain_at = (chain_at + 1) % chain_n; tmp.b = chain + (size_t)chain_at * chain_stride; }      // (keys.b, the chain's first array, is not read by this pass)
             if (timed) RS_CHECK(hipEventRecord(scratch.ev[0], s));
             launch_scatter_any(s, has_b, has_c, false, tiles0, from->src, tmp, from->n, shift, mask, th, scratch.xcd_group, 0u, from->world, (u32)from->fmode, from->me);
             if (timed) RS_CHECK(hipEventRecord(scratch.ev[1], s));

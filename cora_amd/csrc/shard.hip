@@ -55,7 +55,23 @@ struct ShardState {
     FinishStats fst;
     double host_ms = 0;
     std::chrono::steady_clock::time_point t_begin;
+    bool host_gather = false;           // in-process ranks: <Inexact> bytes stay in the host buffer (shard_set_host_gather)
+    int b_chain = 1;                    // arrays the seed sketches' second word climbs through during its sort (radix_sort.hip)
 };
+
+// arrays of the chain the seed sketches' second word climbs through during a rank's sort: three when the rank cuts its arrays from an
+// arena (large references), else the plain ping-pong; CORA_B_CHAIN=n forces n (tests run the chained sorts on small references)
+static int shard_b_chain(const cora_hip_job *job)
+{
+    const int env = getenv("CORA_B_CHAIN") ? atoi(getenv("CORA_B_CHAIN")) : 0;
+    if (env >= 1 && env <= 5) return env;
+    return job->pool.arena ? 3 : 1;
+}
+
+void shard_set_host_gather(cora_hip_job *job, bool on)
+{
+    if (job->shard) job->shard->host_gather = on;
+}
 
 void shard_state_free(cora_hip_job *job)
 {
@@ -132,6 +148,9 @@ extern "C" int cora_hip_shard_begin(cora_hip_job *job, int rank, int world)
     job->sort_timing = SortTiming();
     job->sort_timing.enabled = true;
     sh->t_begin = std::chrono::steady_clock::now();
+    // a large reference: this rank's stage arrays are cut from one allocation, as in the single-GPU run (DevPool, job.hip)
+    reserve_job_arena(job, world, sh->filter);
+    job->pool.ranges.big_from_high = false;
     RCQ(st_pack(job));
     // every contig must own at least one window (HTS:2530); no rank sees every window, so ask the validity bitmap
     launch_contig_scan(job->stream, dp, job->bad.p, job->ctr.p);
@@ -239,8 +258,14 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
             if (radix_sort_count_kept(s, from, lo, lo + 32, job->sort_scratch, &kept)) return fail(100, "radix sort failed");
             if (kept) {
                 RCQ(sh.recv_a.alloc(kept));
-                if (sh.seed_sketch) RCQ(sh.recv_b.alloc(kept));
-                RCQ(st_seed_verify(job, sh.recv_a, kept, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, &from));
+                // the sketches' second word climbs through a chain of arrays when the arena has the room (job.hip: why)
+                int chain = 1;
+                if (sh.seed_sketch) {
+                    chain = shard_b_chain(job);
+                    if (chain > 1 && sh.recv_b.alloc(kept * (u64)chain)) { chain = 1; (void)hipGetLastError(); }
+                    if (chain == 1) RCQ(sh.recv_b.alloc(kept));
+                }
+                RCQ(st_seed_verify(job, sh.recv_a, kept, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, &from, chain));
             }
             sh.recv_a.release(); sh.send_a.release(); sh.recv_b.release(); sh.send_b.release();
             sh.n_send = sh.n_recv = 0;
@@ -248,7 +273,7 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
             return 0;
         }
         if (sh.seed_sketch && sh.n_recv && !sh.recv_b.p) return fail(19, "the seed records' sketches have not been delivered");
-        if (sh.n_recv) RCQ(st_seed_verify(job, sh.recv_a, sh.n_recv, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr));
+        if (sh.n_recv) RCQ(st_seed_verify(job, sh.recv_a, sh.n_recv, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, nullptr, sh.seed_sketch ? sh.b_chain : 1));
         sh.recv_a.release(); sh.send_a.release(); sh.recv_b.release(); sh.send_b.release();
         job->stats.hom_pairs = sh.ps.n;
         return 0;
@@ -331,7 +356,7 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         // this rank's bytes and counts, for the gather / the sum.  Rank 0's own bytes are the head of the table and are in its
         // host buffer already: they stay there (COLLECT puts the other ranks' bytes behind them) and do not make the round
         // trip through the device
-        sh.n_f2 = sh.rank == 0 ? 0 : job->inexact_bytes.size();
+        sh.n_f2 = (sh.rank == 0 || sh.host_gather) ? 0 : job->inexact_bytes.size();
         RCQ(sh.f2_dev.alloc(sh.n_f2)); RCQ(sh.stat_dev.alloc(N_STATS));
         if (sh.n_f2) HIPQ(hipMemcpyAsync(sh.f2_dev.p, job->inexact_bytes.data(), sh.n_f2, hipMemcpyHostToDevice, s));
         const u64 hs[N_STATS] = {st.inexact_nodes, st.dirty_nodes, st.big_nodes, st.inexact_items, st.hom_pairs, st.candidate_pairs, 0, 0};
@@ -342,6 +367,7 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         st.ms_sort_scatter = job->sort_timing.scatter_ms;
         st.n_sort_scatter = job->sort_timing.scatter_launches;
         st.sort_scatter_bytes = job->sort_timing.scatter_bytes;
+        st.pool_peak_bytes = job->pool.peak_live;
         return 0;
     }
     case ST_COLLECT: {                  // rank 0: the table is the ranks' byte ranges in rank order; counts are the sums
@@ -368,6 +394,16 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     default:
         return fail(19, "unknown shard stage %d", stage);
     }
+}
+
+// room for n sketches arriving from the other ranks: the first of sh.b_chain arrays when the arena has the room for the chain
+// their second word climbs through during the sort (VERIFY), else one array
+static int alloc_recv_b(cora_hip_job *job, ShardState &sh, u64 n)
+{
+    sh.b_chain = shard_b_chain(job);
+    if (sh.b_chain > 1 && sh.recv_b.alloc((n ? n : 1) * (u64)sh.b_chain)) { sh.b_chain = 1; (void)hipGetLastError(); }
+    if (sh.b_chain == 1) RCQ(sh.recv_b.alloc(n));
+    return 0;
 }
 
 static int slot_ref(ShardState &sh, const DevParams &dp, int slot, void **p, u64 *n, u32 *eb)
@@ -435,7 +471,7 @@ extern "C" int cora_hip_shard_slot_import(cora_hip_job *job, int slot, const voi
     switch (slot) {
     case SLOT_RECV_A: RCQ(sh.recv_a.alloc(n)); sh.n_recv = n; dst = sh.recv_a.p; eb = 8; break;
     case SLOT_RECV_C: RCQ(sh.recv_c.alloc(n)); if (n != sh.n_recv) return fail(19, "RECV_C must match RECV_A"); dst = sh.recv_c.p; eb = 4; break;
-    case SLOT_RECV_B: RCQ(sh.recv_b.alloc(n)); if (n != sh.n_recv) return fail(19, "RECV_B must match RECV_A"); dst = sh.recv_b.p; eb = 8; break;
+    case SLOT_RECV_B: if (n != sh.n_recv) return fail(19, "RECV_B must match RECV_A"); RCQ(alloc_recv_b(job, sh, n)); dst = sh.recv_b.p; eb = 8; break;
     case SLOT_REPMASK:
         if (n != job->dp.n_words) return fail(19, "bitmap size mismatch");
         RCQ(sh.repmask_g.alloc(n)); dst = sh.repmask_g.p; eb = 4; break;
@@ -472,7 +508,7 @@ extern "C" int cora_hip_shard_slot_reserve(cora_hip_job *job, int slot, uint64_t
     switch (slot) {
     case SLOT_RECV_A: RCQ(sh.recv_a.alloc(n)); sh.n_recv = n; *ptr = sh.recv_a.p; break;
     case SLOT_RECV_C: if (n != sh.n_recv) return fail(19, "RECV_C must match RECV_A"); RCQ(sh.recv_c.alloc(n)); *ptr = sh.recv_c.p; break;
-    case SLOT_RECV_B: if (n != sh.n_recv) return fail(19, "RECV_B must match RECV_A"); RCQ(sh.recv_b.alloc(n)); *ptr = sh.recv_b.p; break;
+    case SLOT_RECV_B: if (n != sh.n_recv) return fail(19, "RECV_B must match RECV_A"); RCQ(alloc_recv_b(job, sh, n)); *ptr = sh.recv_b.p; break;
     case SLOT_RX_CLS: RCQ(sh.rparts.cls.alloc(n)); sh.rparts.NNS = n; *ptr = sh.rparts.cls.p; break;
     case SLOT_RX_CNT: if (n != sh.rparts.NNS) return fail(19, "RX_CNT must match RX_CLS"); RCQ(sh.rparts.ce.alloc(n)); *ptr = sh.rparts.ce.p; break;
     case SLOT_RX_ENT: RCQ(sh.rparts.ent.alloc(n)); sh.rparts.NE = n; *ptr = sh.rparts.ent.p; break;

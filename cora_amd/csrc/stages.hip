@@ -252,7 +252,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     DBuf<u32> skc_tmp;
     SortArrays ck, ct;
     ck.a = codes.p; ct.a = codes_tmp.p;
-    if (sk_b && b_chain_n > 1 && !from) { ck.b = sk_b; ck.b_chain_n = b_chain_n; ck.b_stride = (size_t)n; ct.b = sk_b + (size_t)n; }      // (ct.b: a place holder, the chain is used)
+    if (sk_b && b_chain_n > 1) { ck.b = sk_b; ck.b_chain_n = b_chain_n; ck.b_stride = (size_t)n; ct.b = sk_b + (size_t)n; }      // (ct.b: a place holder, the chain is used)
     else if (sk_b) { RCQ(skb_tmp.alloc(n)); ck.b = sk_b; ct.b = skb_tmp.p; }               // the sketches travel with their records
     if (sk_c) { RCQ(skc_tmp.alloc(n)); ck.c = sk_c; ct.c = skc_tmp.p; }
     // the records are a (code << 32 | position); with a b array the sort's logical key is a:b, i.e. a's bits sit 64 higher

@@ -96,6 +96,7 @@ class ShardedJob:
         self.job, self.comm = job, comm
         self.filter = filter          # None: the library's choice (world <= 4, CORA_SHARD_FILTER); True / False: forced
         self.kept_own = False         # what the last run did
+        self.report = None            # ... and where its time went (run())
         self.lib = hip.lib()
         self.h = job._h
 
@@ -158,7 +159,25 @@ class ShardedJob:
             self._move(src, dst, counts, self.comm.exchange_counts(counts))
 
     def run(self):
+        """One sharded build.  Leaves in self.report what this rank spent where (wall ms per part of the flow, the waits for slower
+        ranks inside the collectives included) and the bytes it sent to OTHER ranks per exchange: bench.py prints them per rank."""
+        import time
         c, lib, h = self.comm, self.lib, self.h
+        ms, sent = {}, {}
+        t_last = [time.perf_counter()]
+
+        def lap(name):
+            now = time.perf_counter()
+            ms[name] = ms.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+
+        def route(name, pairs, counts):
+            recv_counts = self.comm.exchange_counts(counts)
+            away = sum(n for r, n in enumerate(counts) if r != c.rank)
+            for src, dst in pairs:
+                sent[name] = sent.get(name, 0) + away * self._elem_bytes(src)
+                self._move(src, dst, counts, recv_counts)
+
         torch.cuda.synchronize()
         hip._check(lib.cora_hip_shard_begin(h, c.rank, c.world))
         # K-mer and seed records reach their owner by all-to-all, or -- 2 to 4 ranks, where a GPU pair has one xGMI link
@@ -169,45 +188,79 @@ class ShardedJob:
         if keep_own != bool(on.value):
             hip._check(lib.cora_hip_shard_filter(h, int(keep_own), C.byref(on)))
         self.kept_own = keep_own
+        lap("pack")
         # exact: K-mer records to the owner of their hash range
         counts = self._stage(ST_KMERS)
+        lap("kmer_records")
         if not keep_own:
-            self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], counts)
+            route("kmer_records", [(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], counts)
+            lap("kmer_exchange")
         self._stage(ST_EXACT)
+        lap("exact_classes")
         key = C.c_uint64()
         hip._check(lib.cora_hip_shard_get_first_singleton(h, C.byref(key)))
         mine = NO_SINGLETON if key.value == 0xFFFFFFFFFFFFFFFF else key.value
         glob = c.all_reduce_min_int(mine)
         hip._check(lib.cora_hip_shard_set_first_singleton(h, 0xFFFFFFFFFFFFFFFF if glob == NO_SINGLETON else glob))
-        self._import(SLOT_REPMASK, c.all_reduce_sum(self._export(SLOT_REPMASK)))      # disjoint bits: sum = or
+        mask = self._export(SLOT_REPMASK)
+        if not c.local:
+            sent["bitmap_allreduce"] = 2 * mask.numel() * mask.element_size() * (c.world - 1) // c.world     # a ring moves that much per rank
+        self._import(SLOT_REPMASK, c.all_reduce_sum(mask))      # disjoint bits: sum = or
+        del mask
+        lap("bitmap_allreduce")
         self._stage(ST_PARTS)
+        if c.rank != 0:
+            sent["class_parts"] = sum(self._slot_bytes(sl) for sl in (SLOT_X_CLS, SLOT_X_CNT, SLOT_X_ENT, SLOT_X_DIR))
         self._gather_to_root([(SLOT_X_CLS, SLOT_RX_CLS), (SLOT_X_CNT, SLOT_RX_CNT), (SLOT_X_ENT, SLOT_RX_ENT),
                               (SLOT_X_DIR, SLOT_RX_DIR)])
+        lap("class_parts_to_rank0")
         if c.rank == 0:
             self._stage(ST_MERGE)
+            lap("exact_table_rank0")
         # inexact: seed records to the owner of their code hash, verification there
         self._stage(ST_REPS)
+        lap("representatives")
         for seed in range(1, self.job.d + 2):
             counts = self._stage(ST_SEED, seed)
+            lap("seed_records")
             pairs = [(SLOT_SEND_A, SLOT_RECV_A)]
             on = C.c_int()
             hip._check(lib.cora_hip_shard_seed_sketch(h, C.byref(on)))
             if on.value:                                  # large references: the records' sketches travel along (same answer on every rank)
                 pairs.append((SLOT_SEND_B, SLOT_RECV_B))
             if not keep_own:
-                self._route(pairs, counts)
+                route("seed_records", pairs, counts)
+                lap("seed_exchange")
             self._stage(ST_VERIFY, seed)
+            lap("seed_sort_verify")
         # lists are finished by the owner of their source position; intervals are cut where a position holds no list
         self._stage(ST_ITEMS)
         if not c.local:
             self._import(SLOT_WCOUNT, c.all_reduce_sum(self._export(SLOT_WCOUNT)))
-        self._route([(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], self._stage(ST_ITEM_CUT))
+        lap("items")
+        route("items", [(SLOT_SEND_A, SLOT_RECV_A), (SLOT_SEND_C, SLOT_RECV_C)], self._stage(ST_ITEM_CUT))
+        lap("item_exchange")
         self._stage(ST_FINISH)
+        lap("lists_and_own_table_bytes")
+        if c.rank != 0:
+            sent["table_bytes"] = self._slot_bytes(SLOT_F2)
         self._gather_to_root([(SLOT_F2, SLOT_RX_F2)])
         self._import(SLOT_STATS, c.all_reduce_sum(self._export(SLOT_STATS)))
         if c.rank == 0:
             self._stage(ST_COLLECT)
         torch.cuda.synchronize()
+        lap("table_bytes_to_rank0")
+        self.report = {"rank": c.rank, "kept_own": keep_own, "ms": {k: round(v, 3) for k, v in ms.items()}, "sent_bytes": sent}
+
+    def _elem_bytes(self, slot):
+        n, eb = C.c_uint64(), C.c_uint32()
+        hip._check(self.lib.cora_hip_shard_slot_info(self.h, slot, C.byref(n), C.byref(eb)))
+        return int(eb.value)
+
+    def _slot_bytes(self, slot):
+        n, eb = C.c_uint64(), C.c_uint32()
+        hip._check(self.lib.cora_hip_shard_slot_info(self.h, slot, C.byref(n), C.byref(eb)))
+        return int(n.value) * int(eb.value)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ class Stats(C.Structure):
         "inexact_items", "inexact_nodes", "dirty_nodes", "big_nodes")] + [(n, C.c_float) for n in (
         "ms_pack", "ms_exact", "ms_seeds", "ms_items", "ms_host_finish", "ms_total", "ms_sort_scatter")] + [
         ("n_sort_scatter", C.c_uint32), ("sort_scatter_bytes", C.c_uint64), ("hash_mixed_runs", C.c_uint64),
-        ("full_key_fallback", C.c_uint64), ("seed_sketch", C.c_uint64), ("verify_slots", C.c_uint64)]
+        ("full_key_fallback", C.c_uint64), ("seed_sketch", C.c_uint64), ("verify_slots", C.c_uint64), ("pool_peak_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

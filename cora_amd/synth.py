@@ -204,6 +204,65 @@ def workload_repeat_rich(seed: int = 5, total_len: int = 100_000_000, max_copies
     return contig
 
 
+def family_budget(unit: int, copies: int, div: float, K: int = 50, d: int = 2):
+    """What one repeat family costs ANY implementation of the reference's semantics, as (reported pairs, comparisons per seed):
+    two of its copies differ per base with probability q = _pairwise_q(div); a window pair is reported when it has 1..d
+    mismatches (Binomial(K, q)), and is compared under a seed when its 16 seed bases agree ((1-q)^16) -- for every one of
+    the unit * copies^2 / 2 window pairs (homTable_setup.cpp:2753-2762 walks the whole chain of an equal code)."""
+    import math
+    q = _pairwise_q(div)
+    p_rep = sum(math.comb(K, k) * q ** k * (1 - q) ** (K - k) for k in range(1, d + 1))
+    wp = unit * copies * (copies - 1) / 2.0
+    return wp * p_rep, wp * (1 - q) ** 16
+
+
+# BASELINE configs[4] at its stated size (SURVEY.md section 8d.5): copy numbers from 10^2 to 3 x 10^5.  The divergence of every family is
+# chosen so that its REPORTED pairs stay within a budget (family_budget; the sum is 2.4e8 pairs = 4.8e8 directed items, below
+# the 2^32 items the path's 32-bit item indices hold -- the reference's own pair files grow the same way): the more copies,
+# the older the family, as in real genomes.  Equal-code runs among the representatives reach copies * (1-div)^16:
+# 6 000 records for the 10^5-copy family, 8 000 for the 3 x 10^5-copy one; comparisons per seed 1.2e10 in all.
+REPEAT_RICH_GBP_FAMILIES = [(150, 300_000, 0.20), (150, 100_000, 0.16), (300, 10_000, 0.10), (150, 2_000, 0.03), (300, 900, 0.02),
+                            (600, 300, 0.03), (1200, 100, 0.01)]
+
+
+def workload_repeat_rich_gbp(seed: int = 5, total_len: int = 1_000_000_000, families=None, tandem: int = 10_000_000):
+    """configs[4]: one contig of total_len uniform random bases + the families above (every third copy reverse-complemented,
+    instances at random non-overlapping slots) + ``tandem`` bases each of (AT)n and (A)n: exact classes of tandem / 2 and
+    tandem entries, the (AT)n ones palindromic (quirk Q2).  Vectorised (10^5 copies per family)."""
+    fams = REPEAT_RICH_GBP_FAMILIES if families is None else families
+    rs = np.random.RandomState(seed)
+    lut = np.zeros(256, dtype=np.uint32)
+    for b in range(256):
+        lut[b] = sum(int(_ACGT[(b >> (2 * k)) & 3]) << (8 * k) for k in range(4))
+    g = lut[np.frombuffer(rs.bytes((total_len + 3) // 4), dtype=np.uint8)].view(np.uint8)[:total_len]
+    slot = max(u for u, _, _ in fams)
+    need = sum(c for _, c, _ in fams)
+    # the two tandem stretches sit at 1/3 and 2/3 of the contig; slots overlapping them are not used
+    a0, a1 = total_len // 3, 2 * total_len // 3
+    ok = np.ones(total_len // slot, dtype=bool)
+    for a in (a0, a1):
+        ok[max(0, a // slot - 1):(a + tandem) // slot + 2] = False
+    free = np.nonzero(ok)[0]
+    assert need <= len(free), "families do not fit"
+    slots = free[rs.permutation(len(free))[:need]]
+    si = 0
+    for unit, copies, div in fams:
+        codes = rs.randint(0, 4, size=unit).astype(np.uint8)
+        m = np.tile(codes, copies)
+        nm = int(rs.binomial(unit * copies, div))
+        idx = rs.randint(0, unit * copies, size=nm)
+        m[idx] = (m[idx] + rs.randint(1, 4, size=nm).astype(np.uint8)) & 3
+        rows = m.reshape(copies, unit)
+        rows[2::3] = 3 - rows[2::3, ::-1]
+        rows = _ACGT[rows]
+        at = slots[si:si + copies].astype(np.int64) * slot
+        si += copies
+        g[(at[:, None] + np.arange(unit, dtype=np.int64)[None, :]).reshape(-1)] = rows.reshape(-1)
+    g[a0:a0 + tandem] = np.resize(np.frombuffer(b"AT", dtype=np.uint8), tandem)
+    g[a1:a1 + tandem] = ord("A")
+    return [("repeat_rich", g)]
+
+
 # GRCh38 primary assembly: chr1..22, X, Y, M (bases, incl. N)
 GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
                   133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,

@@ -69,6 +69,7 @@ typedef struct cora_hip_stats {
     uint64_t full_key_fallback;   /* 1 if the exact stage had to redo its sort on the full 128-bit keys */
     uint64_t seed_sketch;         /* 1 if the seed records carried the other seeds' codes through their sorts (large references) */
     uint64_t verify_slots;        /* partners the sorted records could not dismiss: K-mer pairs read from the genome, all seeds */
+    uint64_t pool_peak_bytes;     /* most device memory the job's stage arrays held at once since the job was created (this rank's, in a sharded build) */
 } cora_hip_stats;
 
 typedef struct cora_hip_job cora_hip_job;   /* opaque */

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(hip.Contig) == 16
     assert ctypes.sizeof(hip.Params) == 6 * 4 + 16 + 256
-    assert ctypes.sizeof(hip.Stats) == 11 * 8 + 7 * 4 + 4 + 8 + 16 + 16          # + seed_sketch, verify_slots
+    assert ctypes.sizeof(hip.Stats) == 11 * 8 + 7 * 4 + 4 + 8 + 16 + 16 + 8      # + seed_sketch, verify_slots, pool_peak_bytes
 
 
 def test_executable_argument_errors_need_no_gpu(tmp_path):

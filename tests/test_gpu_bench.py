@@ -32,6 +32,26 @@ def test_gpus_flag_starts_that_many_ranks_and_they_build_one_table_pair():
     for k in ("kmers", "hom_pairs", "inexact_nodes", "exact_nodes"):
         assert one["config"][k] == two["config"][k], k
     assert one["roofline"]["frac"] > 0 and one["cpu_baseline"] is None
+    # every rank reports where its last step's time went and what it sent to the other rank (a bad scaling curve must be readable from the line)
+    assert [r["rank"] for r in two["ranks"]] == [0, 1] and "ranks" not in one
+    for r in two["ranks"]:
+        assert r["flow_ms"]["seed_sort_verify"] > 0 and r["library_stage_ms"]["ms_total"] > 0 and r["kept_own"] == two["config"]["kept_own"]
+        assert r["sent_bytes"]["items"] >= 0 and r["kmers_owned"] > 0
+    assert sum(r["kmers_owned"] for r in two["ranks"]) == one["config"]["kmers"]
+
+
+def test_a_failed_sharded_flow_is_an_error_unless_replicas_are_allowed():
+    """Round-2 review: the first real multi-GPU run must not quietly turn into a replica measurement."""
+    env = dict(os.environ, CORA_BENCH_FAIL_SHARDED="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scale", "0.004", "--steps", "1", "--warmup", "1", "--no-extras"]
+    r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 3 and "sharded flow failed" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run(args + ["--allow-replicas"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and "CORA_BENCH_FAIL_SHARDED" in out["config"]["sharded_flow_failure"]
 
 
 def test_default_line_checks_its_tables_and_times_the_executable():

@@ -97,14 +97,39 @@ def test_config2_two_ranks_sharing_the_gpu_build_the_same_tables(keep_own, monke
     assert st["kmers"] > 2_900_000_000 and st["hom_pairs"] > 100_000_000
 
 
-def test_config3_k64_d3_gbp(tmp_path):
-    """-H 3 -K 64 with -t 24 on 1.08 Gbp (the same generator at scale 0.35): d = 3 compacts contigs above 50 Mbp window by
-    window (HTS:2852-2856, finish.cpp plan_windows) -- nine such contigs here; four seeds, sketches of twelve bytes."""
+def test_config2_eight_ranks_sharing_the_gpu_build_the_same_tables():
+    """configs[2] as it is quoted: EIGHT ranks, records exchanged by all-to-all (what more than four GPUs do), at the full
+    3.09 Gbp -- all eight on the one device of this box, every rank with its own arena cut from an eighth of the memory.  The other way
+    of delivery (every rank keeping its own records out of a scan of all positions) is what 2 to 4 GPUs run and is covered above at two ranks: eight
+    virtual ranks would hold eight copies of all 35 GB of K-mer records on the one GPU at once."""
     hip.init(0)
-    contigs = synth.workload_grch38_like(38, 0.35)
-    assert sum(len(s) > 50_000_000 for _, s in contigs) >= 8
+    contigs = synth.workload_grch38_like(38, 1.0)
+    image, W, geom = synth.fasta_image(contigs, 60)
+    del contigs
+    job = hip.Job(50, 2, helpers.split_path("phys", 10), helpers.split_path("par", 8))
+    job.set_reference(image, W, geom)
+    del image
+    job.run_multi(8, [0] * 8)
+    e, en, x, xn = job.tables()
+    st = job.stats()
+    job.close()
+    assert (hashlib.sha256(e).hexdigest(), hashlib.sha256(x).hexdigest()) == CONFIG2_SHA256
+    assert st["kmers"] > 2_900_000_000 and st["hom_pairs"] > 100_000_000 and st["seed_sketch"] == 1
+
+
+DEVICE_MEMORY = 288 * (1 << 30)
+
+
+def test_config3_k64_d3_grch38_sized(tmp_path):
+    """BASELINE configs[3] at its stated size: -H 3 -K 64 with -t 24 on the 3.09 Gbp GRCh38-sized reference.  d = 3 compacts contigs
+    above 50 Mbp window by window (HTS:2852-2856, finish.cpp plan_windows) -- 22 such contigs here; four seeds, sketches of twelve
+    bytes (20-byte records through the seed sorts).  The most the stage arrays hold at once must stay below the device's memory."""
+    hip.init(0)
+    contigs = synth.workload_grch38_like(38, 1.0)
+    assert sum(len(s) > 50_000_000 for _, s in contigs) >= 20
     st, out = _build_and_check(contigs, 64, 3, 10, 24, tmp_path, repeat=False)
-    assert st["kmers"] > 1_000_000_000 and st["seed_sketch"] == 1 and st["hom_pairs"] > 10_000_000
+    assert st["kmers"] > 2_900_000_000 and st["seed_sketch"] == 1 and st["hom_pairs"] > 100_000_000 and st["full_key_fallback"] == 0
+    assert 0 < st["pool_peak_bytes"] < DEVICE_MEMORY - (24 << 30), st["pool_peak_bytes"]
 
 
 def _repeat_rich(seed, total, fams, tandem):
@@ -124,6 +149,20 @@ def test_config4_repeat_rich_100m(tmp_path):
     fams = [(300, 10_000, 0.10, 3), (150, 30_000, 0.15, 3), (600, 300, 0.03, 3), (300, 900, 0.02, 2), (1200, 40, 0.01, 2)]
     st, out = _build_and_check(_repeat_rich(5, 100_000_000, fams, 1_000_000), 50, 2, 10, 8, tmp_path)
     assert st["candidate_pairs"] > 1_000_000_000 and st["hom_pairs"] > 10_000_000 and st["big_nodes"] > 1000
+
+
+def test_config4_repeat_rich_gbp(tmp_path):
+    """BASELINE configs[4] at its stated size: 1 Gbp, families of 3 x 10^5, 10^5 and 10^4 copies (each at a divergence that keeps its
+    REPORTED pairs within the budget synth.family_budget states -- 2.4e8 pairs in all, 4.8e8 directed items < 2^32 -- while
+    their equal-code runs reach 8 000 records and the comparisons 1.2e10 per seed), thousands of copies at 1-3 %, and 10 Mbp
+    each of (AT)n and (A)n: exact classes of 5 x 10^6 (palindromic, listed twice) and 10^7 entries."""
+    hip.init(0)
+    pairs = sum(synth.family_budget(u, c, d)[0] for u, c, d in synth.REPEAT_RICH_GBP_FAMILIES)
+    assert 1e8 < pairs < (1 << 31) and max(c for _, c, _ in synth.REPEAT_RICH_GBP_FAMILIES) >= 100_000
+    st, out = _build_and_check(synth.workload_repeat_rich_gbp(5, 1_000_000_000), 50, 2, 10, 8, tmp_path, repeat=False)
+    assert st["kmers"] > 950_000_000 and st["candidate_pairs"] > 10_000_000_000 and st["big_nodes"] > 100_000
+    assert 0.5 * pairs < st["hom_pairs"] < 2.0 * pairs, (st["hom_pairs"], pairs)          # the budget's arithmetic holds
+    assert st["exact_classes"] > 0 and 0 < st["pool_peak_bytes"] < DEVICE_MEMORY - (24 << 30)
 
 
 @pytest.mark.parametrize("sketch", ["0", "1"])

@@ -42,6 +42,7 @@ def test_sharded_ranks_over_gloo_equal_reference(world, keep_own, tmp_path):
         env["CORA_SHARD_FILTER"] = keep_own
     if world == 3:
         env["CORA_SKETCH"] = "1"       # the seed records carry sketches (what a large reference switches on): one more slot to move
+        env["CORA_B_CHAIN"] = "3"      # ... and their second word climbs through a chain of arrays during the sort, as in a rank's arena
     procs = [subprocess.Popen([sys.executable, script, str(r), str(world)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     outs = [p.communicate(timeout=280)[0] for p in procs]
@@ -86,6 +87,7 @@ def test_in_process_ranks_equal_reference(world, sketch, keep_own, monkeypatch):
         monkeypatch.setenv("CORA_SHARD_FILTER", keep_own)
     if sketch:
         monkeypatch.setenv("CORA_SKETCH", sketch)      # sketches travel with the seed records, as on a large reference
+        monkeypatch.setenv("CORA_B_CHAIN", "3" if world == 3 else "5")     # ... through the chained sort a rank with an arena runs (kept and exchanged records)
     for name in CASES:
         c, want = helpers.golden_case(name)
         job = hip.Job(c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
