@@ -67,6 +67,17 @@ extern "C" int cora_hip_job_create(const cora_hip_params *params, cora_hip_job *
     return 0;
 }
 
+int job_side_context(cora_hip_job *job, cora_hip_job **out)
+{
+    cora_hip_job *c = nullptr;
+    RCQ(cora_hip_job_create(&job->prm, &c));
+    c->device = job->device;
+    c->sketch_mode = job->sketch_mode; c->hash_bits = job->hash_bits; c->host_threads = job->host_threads;
+    if (c->ctr.alloc(1)) { cora_hip_job_destroy(c); return fail(101, "device allocation failed"); }
+    *out = c;
+    return 0;
+}
+
 extern "C" void cora_hip_job_destroy(cora_hip_job *job)
 {
     if (!job) return;

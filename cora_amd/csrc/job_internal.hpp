@@ -325,6 +325,9 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
                    const SortSource *from = nullptr, int b_chain_n = 1 /* sk_b is the first of that many arrays of n words (radix_sort's chain) */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
+// a second context on the job's device for work that runs beside the job's own stream (shard.hip: the exact table's finish):
+// own stream, events, counters, sort scratch and pool; no reference of its own (the caller copies dp / hg from the job)
+int job_side_context(cora_hip_job *job, cora_hip_job **out);
 // in-process ranks (multi.hip): FINISH leaves this rank's <Inexact> bytes in its host buffer only -- the ranks share the address
 // space, so they are copied host to host into rank 0's table instead of going through the device (SLOT_F2 stays empty)
 void shard_set_host_gather(cora_hip_job *job, bool on);

@@ -31,6 +31,21 @@
 
 using namespace cora;
 
+// Rank 0's finish of the exact table (ST_MERGE: all classes by representative, block merge, <Exact> bytes; 9-11 ms of small,
+// latency-bound kernels at 3.09 Gbp) runs BESIDE the stages that follow instead of holding rank 0 back while the other ranks
+// go on to their seeds and then wait for it at the next exchange: a helper thread with a context of its own -- stream,
+// counters, sort scratch, device pool, host buffers; it shares the device arrays of the reference -- that is joined before
+// rank 0 finishes its lists.  (Round-2 review: "remove the rank-0 funnel".  Splitting the merge by representative range would
+// need one more exchange of the class parts with cuts chosen where no block crosses; hiding it costs no exchange.)
+struct MergeSide {
+    cora_hip_job *ctx = nullptr;
+    std::thread th;
+    int rc = 0;
+    std::string err;
+    FinishStats fst;
+    double host_ms = 0;
+};
+
 struct ShardState {
     int rank = 0, world = 1;
     bool filter = false;                // K-mer and seed records: scan everything and keep the own ones, instead of the exchange
@@ -55,6 +70,7 @@ struct ShardState {
     FinishStats fst;
     double host_ms = 0;
     std::chrono::steady_clock::time_point t_begin;
+    MergeSide *side = nullptr;          // rank 0: the exact table's finish beside the seeds stage
     bool host_gather = false;           // in-process ranks: <Inexact> bytes stay in the host buffer (shard_set_host_gather)
     int b_chain = 1;                    // arrays the seed sketches' second word climbs through during its sort (radix_sort.hip)
 };
@@ -73,10 +89,31 @@ void shard_set_host_gather(cora_hip_job *job, bool on)
     if (job->shard) job->shard->host_gather = on;
 }
 
+// waits for the exact table's finish (if one is running), takes its result over; the class parts are released by the caller's thread
+static int join_merge(cora_hip_job *job, ShardState &sh)
+{
+    if (!sh.side || !sh.side->th.joinable()) return 0;
+    MergeSide &m = *sh.side;
+    m.th.join();
+    sh.rparts.release_all(); sh.parts.release_all();
+    if (m.rc) { g_err = m.err; return m.rc; }
+    ByteBuf &a = job->exact_bytes, &b = m.ctx->exact_bytes;
+    std::swap(a.p, b.p); std::swap(a.n, b.n); std::swap(a.cap, b.cap); std::swap(a.mapped, b.mapped);
+    sh.fst.exact_nodes = m.fst.exact_nodes;
+    sh.host_ms += m.host_ms;
+    return 0;
+}
+
 void shard_state_free(cora_hip_job *job)
 {
     if (!job->shard) return;
     PoolScope scope(&job->pool);
+    if (job->shard->side) {
+        if (job->shard->side->th.joinable()) job->shard->side->th.join();
+        job->shard->rparts.release_all(); job->shard->parts.release_all();
+        if (job->shard->side->ctx) { PoolScope none(nullptr); cora_hip_job_destroy(job->shard->side->ctx); }
+        delete job->shard->side;
+    }
     delete job->shard;
     job->shard = nullptr;
 }
@@ -213,8 +250,29 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         return 0;
     }
     case ST_MERGE: {
-        RCQ(st_exact_finish(job, sh.rparts, sh.fst, sh.host_ms));
-        sh.rparts.release_all(); sh.parts.release_all();
+        if (getenv("CORA_MERGE_INLINE")) {                  // (debugging: on the job's own stream, as before round 3)
+            RCQ(st_exact_finish(job, sh.rparts, sh.fst, sh.host_ms));
+            sh.rparts.release_all(); sh.parts.release_all();
+            return 0;
+        }
+        RCQ(join_merge(job, sh));
+        if (!sh.side) sh.side = new MergeSide();
+        MergeSide &m = *sh.side;
+        if (!m.ctx) {
+            PoolScope none(nullptr);
+            RCQ(job_side_context(job, &m.ctx));
+        }
+        m.ctx->prm = job->prm; m.ctx->hg = job->hg; m.ctx->dp = job->dp; m.ctx->host_threads = job->host_threads;
+        m.rc = 0; m.err.clear(); m.fst = FinishStats(); m.host_ms = 0;
+        HIPQ(hipStreamSynchronize(s));                      // the class parts are all there
+        ShardState *shp = &sh;
+        m.th = std::thread([job, shp] {
+            MergeSide &mm = *shp->side;
+            if (hipSetDevice(job->device) != hipSuccess) { mm.rc = 100; mm.err = "hipSetDevice failed in the exact table's helper thread"; return; }
+            PoolScope own(&mm.ctx->pool);
+            mm.rc = st_exact_finish(mm.ctx, shp->rparts, mm.fst, mm.host_ms);
+            if (mm.rc) mm.err = g_err;
+        });
         return 0;
     }
     case ST_REPS: {
@@ -347,6 +405,7 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         return 0;
     }
     case ST_FINISH: {
+        RCQ(join_merge(job, sh));                           // rank 0: the exact table, finished beside the seeds stage
         if (!sh.recv_a.p) { RCQ(sh.recv_a.alloc(1)); RCQ(sh.recv_c.alloc(1)); }
         RCQ(st_items_finish(job, sh.recv_a, sh.recv_c, sh.n_recv, sh.fst, sh.host_ms));
         sh.recv_a.release(); sh.recv_c.release(); sh.send_a.release(); sh.send_c.release();
