@@ -15,6 +15,7 @@
 //   k_conform                  does every contig keep the fixed line width?  (then the image is used as it is)
 //   k_compact                  otherwise: the $1 bytes of the sequence lines, contig after contig, one wave per line
 #include "job_internal.hpp"
+#include <chrono>
 #include <thread>
 
 using namespace cora;
@@ -233,8 +234,8 @@ namespace {
 // time).  Here a few host threads copy alternate chunks into pinned buffers of their own and send each on its way at once.
 int upload_pageable(u8 *dst, const u8 *src, size_t bytes, hipStream_t s)
 {
-    constexpr size_t CHUNK = 8u << 20;
-    constexpr int WORKERS = 6;
+    static const size_t CHUNK = (size_t)(getenv("CORA_UPLOAD_CHUNK_MB") ? atoi(getenv("CORA_UPLOAD_CHUNK_MB")) : 8) << 20;
+    static const int WORKERS = getenv("CORA_UPLOAD_WORKERS") ? std::max(1, std::min(32, atoi(getenv("CORA_UPLOAD_WORKERS")))) : 6;
     if (bytes < (size_t)64 * CHUNK) { HIPQ(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s)); return 0; }
     int dev = 0;
     HIPQ(hipGetDevice(&dev));
@@ -273,8 +274,13 @@ int scan_impl(cora_hip_fasta *f, const u8 *image, size_t bytes)
     f->n = bytes;
     const bool virt_nl = bytes && image[bytes - 1] != '\n';   // awk treats an unterminated last line as a record
     f->n_scan = bytes + (virt_nl ? 1 : 0);
+    static const bool trace = getenv("CORA_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     RCQ(f->img.alloc(f->n_scan + 64));
+    if (trace) fprintf(stderr, "[cora] fasta: image buffer of %zu bytes after %.3f ms\n", bytes, since());
     if (bytes) RCQ(upload_pageable(f->img.p, image, bytes, s));          // (returns when a large image has arrived)
+    if (trace) fprintf(stderr, "[cora] fasta: image uploaded after %.3f ms\n", since());
     HIPQ(hipMemsetAsync(f->img.p + bytes, 0, f->n_scan + 64 - bytes, s));
     if (virt_nl) HIPQ(hipMemsetAsync(f->img.p + bytes, '\n', 1, s));
 
@@ -381,6 +387,7 @@ int scan_impl(cora_hip_fasta *f, const u8 *image, size_t bytes)
     in.image_bytes = bytes; in.lines = n_lines; in.contigs = nc; in.bases = bases;
     in.conforming = violations == 0; in.line_width = (int32_t)W;
     HIPQ(hipEventElapsedTime(&in.ms_scan, ev[0], ev[1]));
+    if (trace) fprintf(stderr, "[cora] fasta: scanned after %.3f ms (kernels %.3f ms)\n", since(), in.ms_scan);
     return 0;
 }
 
@@ -394,7 +401,9 @@ int cora_hip_fasta_scan(const uint8_t *image, size_t image_bytes, cora_hip_fasta
     if (g_device < 0) return fail(102, "cora_hip_init has not succeeded");
     PoolScope no_pool(nullptr);
     cora_hip_fasta *f = new cora_hip_fasta();
+    const auto t0 = std::chrono::steady_clock::now();
     const int rc = scan_impl(f, image, image_bytes);
+    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] fasta: scan and release of its temporaries %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (rc) { delete f; return rc; }
     *out = f;
     return 0;

@@ -1,7 +1,9 @@
 // finish.cpp -- host side of the table build (see finish.hpp).
 // HTS = /root/reference/homTable_setup.cpp.
 #include "finish.hpp"
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <unistd.h>
 #include "kernels.hpp"
 
 #include <algorithm>
@@ -83,6 +85,14 @@ static void bytebuf_release(ByteBuf &b)
 bool ByteBuf::reserve_uninit(size_t c)
 {
     if (c <= cap && p) return true;
+    if (fd >= 0) {                           // the file grows and is mapped anew; what it holds stays
+        const size_t len = ((c ? c : 1) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (ftruncate(fd, (off_t)len) != 0) return false;
+        void *m = p ? mremap(p, mapped, len, MREMAP_MAYMOVE) : mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (uint8_t *)m; mapped = len; cap = c;
+        return true;
+    }
     bytebuf_release(*this);
     if (c >= ((size_t)32 << 20)) {
         const size_t len = (c + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
@@ -98,7 +108,40 @@ bool ByteBuf::reserve_uninit(size_t c)
     if (!p) n = 0;
     return p != nullptr;
 }
-ByteBuf::~ByteBuf() { bytebuf_release(*this); }
+bool ByteBuf::grow_keep(size_t c)
+{
+    if (c <= cap && p) return true;
+    if (fd >= 0 || !p || !n) return reserve_uninit(c);
+    ByteBuf grown;
+    if (!grown.reserve_uninit(c)) return false;
+    memcpy(grown.p, p, n);
+    std::swap(p, grown.p); std::swap(cap, grown.cap); std::swap(mapped, grown.mapped);
+    return true;
+}
+bool ByteBuf::open_file(const char *path)
+{
+    if (fd >= 0) { if (mapped) munmap(p, mapped); close(fd); fd = -1; p = nullptr; mapped = 0; cap = 0; }
+    else bytebuf_release(*this);
+    n = 0;
+    fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    return fd >= 0;
+}
+bool ByteBuf::close_file()
+{
+    if (fd < 0) return false;
+    bool ok = true;
+    if (mapped && munmap(p, mapped) != 0) ok = false;
+    if (ftruncate(fd, (off_t)n) != 0) ok = false;
+    if (close(fd) != 0) ok = false;
+    fd = -1; p = nullptr; mapped = 0; cap = 0;
+    return ok;
+}
+ByteBuf::~ByteBuf()
+{
+    if (fd >= 0) { if (mapped) munmap(p, mapped); close(fd); fd = -1; p = nullptr; mapped = 0; }
+    else bytebuf_release(*this);
+}
+
 
 namespace {
 

@@ -57,8 +57,16 @@ struct InexactDeviceResult {           // directed items sorted by (source, targ
 struct ByteBuf {
     uint8_t *p = nullptr;
     size_t n = 0, cap = 0;
-    size_t mapped = 0;                   // > 0: p is an anonymous mapping of that many bytes (large buffers: huge pages asked for)
-    bool reserve_uninit(size_t c);       // false: the host is out of memory (the buffer is then empty, p == nullptr)
+    size_t mapped = 0;                   // > 0: p is a mapping of that many bytes (large buffers: anonymous, huge pages asked for; or the file's)
+    int fd = -1;                         // >= 0: the buffer IS a file (open_file): p is a shared mapping of it, what is written is the file's content
+    bool reserve_uninit(size_t c);       // false: the host is out of memory (the buffer is then empty, p == nullptr).  A file-backed buffer keeps its content.
+    bool grow_keep(size_t c);            // room for c bytes, the first n bytes kept
+    // The buffer becomes the file `path` (created / truncated): a table assembled in it needs no fwrite afterwards -- on the GPU
+    // boxes an 894 MB fwrite takes 116 ms, copying into already touched pages of a shared mapping 30 ms and its first touch, which
+    // can be done beside the kernels, 90 ms (profiles/io_probe.cpp).  close_file() cuts the file to n bytes and closes it; the
+    // buffer is empty afterwards.  Both return false on an I/O error.
+    bool open_file(const char *path);
+    bool close_file();
     const uint8_t *data() const { return p; }
     size_t size() const { return n; }
     ~ByteBuf();

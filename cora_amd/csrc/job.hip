@@ -82,6 +82,7 @@ extern "C" void cora_hip_job_destroy(cora_hip_job *job)
 {
     if (!job) return;
     join_warm(job);
+    join_exact_writer(job);
     multi_state_free(job);
     (void)hipSetDevice(job->device);
     shard_state_free(job);
@@ -216,6 +217,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     if (!job || !job->have_ref) return fail(51, "no reference set");
     PoolScope pool_scope(&job->pool);
     shard_state_free(job);                                 // (what a sharded run of this job left, e.g. one that failed half-way)
+    join_exact_writer(job);
+    job->exact_written = false;
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
     cora_hip_stats &st = job->stats;
@@ -253,10 +256,21 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         job->warm = std::thread([job, est, dev, packed_words] {
             if (hipSetDevice(dev) != hipSuccess) return;
             auto touch = [](const volatile uint8_t *p, size_t n) { uint8_t x = 0; for (size_t o = 0; o < n; o += 4096) x ^= p[o]; return x; };
+            // (the table's pages in a thread of their own: when the buffer is the table's file -- cora_hip_job_set_table_files -- their
+            //  first touch takes 90 ms per 0.9 GB, in ONE thread: several threads touching one file's pages are slower, profiles/io_probe.cpp)
+            static const bool trace = getenv("CORA_TRACE") != nullptr;
+            const auto w0 = std::chrono::steady_clock::now();
+            auto since = [w0] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); };
+            std::thread table([job, est, since] {
+                if (job->inexact_bytes.reserve_uninit(est))
+                    for (size_t o = 0; o < est; o += 4096) job->inexact_bytes.p[o] = 0;
+                if (trace) fprintf(stderr, "[cora] warm: table pages touched after %.1f ms\n", since());
+            });
             if (!job->h_packed.reserve(packed_words)) (void)touch((const uint8_t *)job->h_packed.p, packed_words * sizeof(u64));
+            if (trace) fprintf(stderr, "[cora] warm: packed-reference landing area pinned after %.1f ms\n", since());
             if (!job->h_stream.reserve(est)) (void)touch(job->h_stream.p, est);
-            if (job->inexact_bytes.reserve_uninit(est))
-                for (size_t o = 0; o < est; o += 4096) job->inexact_bytes.p[o] = 0;
+            if (trace) fprintf(stderr, "[cora] warm: byte-stream landing area pinned after %.1f ms\n", since());
+            table.join();
         });
     } else {
         // the packed reference starts its way to the host now (0.25 B per base over PCIe beside 0.8 s of kernels): lists
@@ -297,6 +311,16 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         x.release_all();
         HIPQ(hipEventRecord(job->ev[2], s));
         RCQ(st_exact_finish(job, parts, fst, host_ms));
+        if (!job->exact_path.empty()) {                    // <Exact> goes to its file now, beside the inexact stages (9 ms of fwrite for 68 MB)
+            job->exact_write_failed = false;
+            job->exact_writer = std::thread([job] {
+                FILE *f = fopen(job->exact_path.c_str(), "wb");
+                const size_t n = job->exact_bytes.size();
+                const bool ok = f && (n == 0 || fwrite(job->exact_bytes.data(), 1, n, f) == n);
+                if (!(f && fclose(f) == 0 && ok)) job->exact_write_failed = true;
+            });
+            job->exact_written = true;
+        }
     }
 
     job->pool.ranges.big_from_high = arena_end == 1;
@@ -401,6 +425,39 @@ extern "C" int cora_hip_job_tables(const cora_hip_job *job, const uint8_t **exac
     if (inexact) *inexact = job->inexact_bytes.data();
     if (inexact_bytes) *inexact_bytes = job->inexact_bytes.size();
     if (inexact_nodes) *inexact_nodes = job->stats.inexact_nodes;
+    return 0;
+}
+
+extern "C" int cora_hip_job_set_table_files(cora_hip_job *job, const char *exact_path, const char *inexact_path)
+{
+    if (!job || !exact_path || !inexact_path) return fail(19, "null argument");
+    join_warm(job);
+    join_exact_writer(job);
+    job->exact_path = exact_path;
+    if (!job->inexact_bytes.open_file(inexact_path)) return fail(68, "Can't write to file: %s", inexact_path);                 // HTS:1451-1456
+    return 0;
+}
+
+extern "C" int cora_hip_job_finish_table_files(cora_hip_job *job)
+{
+    if (!job) return fail(19, "null job");
+    join_warm(job);
+    join_exact_writer(job);
+    bool ok = true;
+    if (job->inexact_bytes.fd >= 0) ok = job->inexact_bytes.close_file();
+    if (!job->exact_path.empty()) {
+        if (job->exact_written) ok = ok && !job->exact_write_failed;
+        else {                                             // (a build over several ranks: the exact table came from rank 0's helper context)
+            FILE *f = fopen(job->exact_path.c_str(), "wb");
+            const size_t n = job->exact_bytes.size();
+            const bool w = f && (n == 0 || fwrite(job->exact_bytes.data(), 1, n, f) == n);
+            ok = ok && f && fclose(f) == 0 && w;
+        }
+    }
+    const std::string ep = job->exact_path;
+    job->exact_path.clear();
+    job->exact_written = false;
+    if (!ok) return fail(68, "Can't write to file: %s (or the <Inexact> file beside it)", ep.c_str());                           // HTS:2485-2489
     return 0;
 }
 

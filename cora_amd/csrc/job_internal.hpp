@@ -235,10 +235,16 @@ struct cora_hip_job {
     // First build of a job on a large reference: a helper thread pins h_stream and faults in the pages of inexact_bytes
     // beside the kernels (job.hip); whoever touches either buffer calls join_warm first.
     std::thread warm;
+    // cora_hip_job_set_table_files: <Inexact> is assembled in a mapping of its file (inexact_bytes is then file-backed), <Exact> is
+    // written by a helper thread as soon as it is finished, beside the inexact stages
+    std::string exact_path;
+    std::thread exact_writer;
+    bool exact_written = false, exact_write_failed = false;
     cora_hip_stats stats;
 };
 
 inline void join_warm(cora_hip_job *job) { if (job->warm.joinable()) job->warm.join(); }
+inline void join_exact_writer(cora_hip_job *job) { if (job->exact_writer.joinable()) job->exact_writer.join(); }
 
 inline int read_counters(cora_hip_job *job, DevCounters &h)
 {

@@ -303,14 +303,8 @@ struct Rank {
             uint64_t total = 0;
             for (int q = 0; q < world; q++) total += t.pub[q].n[0];
             ByteBuf &tb = job->inexact_bytes;
-            if (!tb.p || tb.cap < total + 16) {           // (first build of a job only: later ones find the room of the last table)
-                ByteBuf grown;
-                if (!grown.reserve_uninit(total + 16)) { fail(101, "host allocation of %llu bytes for <Inexact> failed", (unsigned long long)total + 16); fail_with(101); }
-                else {
-                    if (tb.n) memcpy(grown.p, tb.p, tb.n);
-                    std::swap(tb.p, grown.p); std::swap(tb.cap, grown.cap); std::swap(tb.mapped, grown.mapped);
-                }
-            }
+            // (first build of a job only: later ones find the room of the last table)
+            if (!tb.grow_keep(total + 16)) { fail(101, "host allocation of %llu bytes for <Inexact> failed", (unsigned long long)total + 16); fail_with(101); }
             t.pub[0].ptr[1] = (void *)tb.p;
         }
         if (!sync()) return;

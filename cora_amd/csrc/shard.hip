@@ -433,12 +433,8 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         cora_hip_stats &st = job->stats;
         ByteBuf &tb = job->inexact_bytes;
         const size_t own = tb.size(), total = own + sh.n_f2_all;
-        if (!tb.p || tb.cap < total + 16) {             // (first build of a job only: later ones find the room of the last table)
-            ByteBuf grown;
-            if (!grown.reserve_uninit(total + 16)) return fail(101, "host allocation of %llu bytes for <Inexact> failed", (unsigned long long)total + 16);
-            if (own) memcpy(grown.p, tb.p, own);
-            std::swap(tb.p, grown.p); std::swap(tb.cap, grown.cap); std::swap(tb.mapped, grown.mapped);
-        }
+        if (!tb.grow_keep(total + 16))                  // (first build of a job only: later ones find the room of the last table)
+            return fail(101, "host allocation of %llu bytes for <Inexact> failed", (unsigned long long)total + 16);
         if (sh.n_f2_all) HIPQ(hipMemcpyAsync(tb.p + own, sh.f2_all.p, sh.n_f2_all, hipMemcpyDeviceToHost, s));
         u64 hs[N_STATS] = {0};
         if (sh.stat_dev.p) HIPQ(hipMemcpyAsync(hs, sh.stat_dev.p, sizeof hs, hipMemcpyDeviceToHost, s));

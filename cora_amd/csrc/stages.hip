@@ -331,7 +331,11 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
 // F2 bytes (HTS:1353-1432).  ik/im hold M items in any order.
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms)
 {
-    join_warm(job);                                  // (the host buffers this stage fills may still be in preparation)
+    {
+        const auto w0 = std::chrono::steady_clock::now();
+        join_warm(job);                              // (the host buffers this stage fills may still be in preparation)
+        if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] items: waited %.3f ms for the host buffers\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+    }
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
     InexactDeviceResult ir;                 // the items of the lists the host finishes

@@ -20,7 +20,7 @@ BIN_DIR = os.path.join(_HERE, "bin")
 
 EXPORTS = [
     "cora_hip_init", "cora_hip_shutdown", "cora_hip_last_error", "cora_hip_job_create", "cora_hip_job_destroy",
-    "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_run_multi", "cora_hip_device_count", "cora_hip_job_tables", "cora_hip_job_stats",
+    "cora_hip_job_set_reference", "cora_hip_job_run", "cora_hip_job_run_multi", "cora_hip_device_count", "cora_hip_job_tables", "cora_hip_job_stats", "cora_hip_job_set_table_files", "cora_hip_job_finish_table_files",
     "cora_hip_radix_sort", "cora_hip_radix_sort_noalloc", "cora_hip_radix_sort_noalloc_max", "cora_hip_test_sort_host", "cora_hip_test_sort_chain_host", "cora_hip_test_sort_kept_host", "cora_hip_test_list_sort", "cora_hip_test_pack", "cora_hip_test_kmers", "cora_hip_test_window_bits",
     "cora_hip_shard_begin", "cora_hip_shard_stage", "cora_hip_shard_slot_info", "cora_hip_shard_slot_export",
     "cora_hip_shard_slot_import", "cora_hip_shard_slot_reserve", "cora_hip_shard_slot_ptr", "cora_hip_shard_seed_sketch", "cora_hip_shard_filter", "cora_hip_shard_get_first_singleton", "cora_hip_shard_set_first_singleton",
@@ -124,6 +124,8 @@ def lib():
         L.cora_hip_device_count.argtypes = [C.POINTER(C.c_int)]
         L.cora_hip_job_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.cora_hip_job_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.cora_hip_job_set_table_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.cora_hip_job_finish_table_files.argtypes = [C.c_void_p]
         L.cora_hip_radix_sort.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_int, C.c_int]
         L.cora_hip_radix_sort_noalloc.argtypes = [C.c_void_p] * 6 + [C.c_uint64, C.c_int, C.c_int]
         L.cora_hip_radix_sort_noalloc_max.restype = C.c_uint64

@@ -106,6 +106,16 @@ int cora_hip_job_tables(const cora_hip_job *job,
                         const uint8_t **inexact, size_t *inexact_bytes, uint64_t *inexact_nodes);
 int cora_hip_job_stats(const cora_hip_job *job, cora_hip_stats *out);
 
+/* The tables straight into their files, for callers that want files and nothing else (the drop-in executable).  Replaces the fopen /
+ * fwrite / fclose of PrintBinaryEquivData and PrintBinaryHomMapData_SplitAware (HTS:572-635, 1353-1432, 1451-1456, 2485-2489).
+ * Call before cora_hip_job_run[_multi]: <Inexact> is then assembled in a shared mapping of inexact_path (no copy of the 0.8 GB
+ * into the page cache afterwards) and <Exact> is written to exact_path by a helper thread as soon as the exact stage is through,
+ * beside the inexact stages.  cora_hip_job_finish_table_files cuts <Inexact> to its size, closes both files and says whether
+ * every write succeeded (status 68, the reference's "Can't write to file").  Between the two calls cora_hip_job_tables
+ * still shows both tables; after the second the <Inexact> pointer is NULL (the bytes are the file's). */
+int cora_hip_job_set_table_files(cora_hip_job *job, const char *exact_path, const char *inexact_path);
+int cora_hip_job_finish_table_files(cora_hip_job *job);
+
 /* ---- multi-GPU: one process per GPU, no counterpart in the reference (it has no distributed code) ----
  * Every rank holds the packed reference, scans 1/R of the positions and owns 1/R of the key space.  The
  * library computes per rank; the caller moves the "slots" between ranks with its collective library
