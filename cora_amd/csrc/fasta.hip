@@ -214,6 +214,10 @@ u32 grid_of(u64 n, u32 per) { const u64 g = (n + per - 1) / per; return (u32)(g 
 }  // namespace
 
 struct cora_hip_fasta {
+    // Every device array of the scan -- the ones kept below and its temporaries -- comes from this pool, so that nothing is given
+    // back to the driver (hipFree synchronises the device, and the dozen releases at the end of a 3.1 GB scan took 11 ms, 163 ms in
+    // the first process on a freshly leased GPU box) before cora_hip_fasta_destroy.  Declared first: it outlives the arrays.
+    DevPool pool;
     hipStream_t stream = nullptr;
     u64 n = 0, n_scan = 0, n_lines = 0, nc = 0, bases = 0;
     DBuf<u8> img;
@@ -224,7 +228,12 @@ struct cora_hip_fasta {
     std::vector<u64> line_bases;          // the awk program's lineBases per contig (stale values included)
     std::string fai;
     cora_hip_fasta_info info;
-    ~cora_hip_fasta() { if (stream) (void)hipStreamDestroy(stream); }
+    ~cora_hip_fasta()
+    {
+        if (stream) (void)hipStreamDestroy(stream);
+        img.release(); NL.release(); H.release(); P.release(); tok_at.release(); tok_len.release(); hdr_flag.release();
+        pool.destroy();
+    }
 };
 
 namespace {
@@ -235,7 +244,9 @@ namespace {
 int upload_pageable(u8 *dst, const u8 *src, size_t bytes, hipStream_t s)
 {
     static const size_t CHUNK = (size_t)(getenv("CORA_UPLOAD_CHUNK_MB") ? atoi(getenv("CORA_UPLOAD_CHUNK_MB")) : 8) << 20;
-    static const int WORKERS = getenv("CORA_UPLOAD_WORKERS") ? std::max(1, std::min(32, atoi(getenv("CORA_UPLOAD_WORKERS")))) : 6;
+    // three workers: 75-78 ms for the 3.1 GB image with 2 to 4 of them, 83-90 ms with 6 or 12 (profiles/e2e_variants.py; reading the page
+    // cache is not the limit -- 6 threads copy 70-100 GB/s there, profiles/io_probe.cpp -- the copy engines' queue is)
+    static const int WORKERS = getenv("CORA_UPLOAD_WORKERS") ? std::max(1, std::min(32, atoi(getenv("CORA_UPLOAD_WORKERS")))) : 3;
     if (bytes < (size_t)64 * CHUNK) { HIPQ(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s)); return 0; }
     int dev = 0;
     HIPQ(hipGetDevice(&dev));
@@ -399,8 +410,8 @@ int cora_hip_fasta_scan(const uint8_t *image, size_t image_bytes, cora_hip_fasta
 {
     if ((!image && image_bytes) || !out) return fail(51, "null argument");
     if (g_device < 0) return fail(102, "cora_hip_init has not succeeded");
-    PoolScope no_pool(nullptr);
     cora_hip_fasta *f = new cora_hip_fasta();
+    PoolScope own_pool(&f->pool);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = scan_impl(f, image, image_bytes);
     if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] fasta: scan and release of its temporaries %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

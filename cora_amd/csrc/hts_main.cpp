@@ -209,8 +209,9 @@ int main(int argc, char **argv)
     if (!rc) rc = cora_hip_job_set_reference_fasta(job, fa);
     if (!rc) rc = cora_hip_job_set_table_files(job, exact_out.c_str(), inexact_out.c_str());
     const double ms_setref = ms_since(t_start);
-    cora_hip_fasta_destroy(fa);
-    if (getenv("CORA_TRACE")) std::cerr << "[cora] scan done at " << ms_scan << " ms, reference set at " << ms_setref << ", scan object destroyed at " << ms_since(t_start) << std::endl;
+    // (the scan object -- 7 GB of device arrays for a 3.1 Gbp reference -- is given back after the tables are written, not here:
+    //  a release synchronises the device and can be slow on a fresh box; 288 GB hold the build beside it)
+    if (getenv("CORA_TRACE")) std::cerr << "[cora] scan done at " << ms_scan << " ms, reference set at " << ms_setref << std::endl;
     const double ms_load = ms_since(t_start);
     // Every GPU of the node takes part (cora starts ONE process, cora.cpp:1586): one host thread per GPU, records exchanged
     // peer to peer.  A reference below 256 Mbp is built on one GPU (the exchanges would cost more than they save).
@@ -269,11 +270,12 @@ int main(int argc, char **argv)
     std::cout << "e2e_ms: args+splits+mmap " << ms_parse << "  device_init " << ms_init - ms_parse << "  read+upload+scan " << ms_load - ms_init
               << "  build(incl. tables to host) " << ms_build - ms_load << "  write_files " << ms_since(t_start) - ms_build
               << "  total " << ms_since(t_start) << std::endl;
-    // (Leaving through _exit without giving the device memory back is SLOWER: 1.10 s of wall time against 0.91 s with the orderly
-    //  teardown below -- the driver takes 0.26 s to reclaim a 190 GiB arena of a process that just ends, hipFree takes 17 ms.)
+    cora_hip_fasta_destroy(fa);
     cora_hip_job_destroy(job);
     if (getenv("CORA_TRACE")) std::cerr << "[cora] job destroyed at " << ms_since(t_start) << " ms" << std::endl;
     cora_hip_shutdown();
     if (getenv("CORA_TRACE")) std::cerr << "[cora] shut down at " << ms_since(t_start) << " ms" << std::endl;
+    // (Leaving through _exit here, to skip the HIP / HSA runtime's own teardown, makes the process take 1.08 instead of 0.89 s: the
+    //  kernel driver then tears the process's GPU state down itself, which is the slower way -- measured with profiles/e2e_variants.py.)
     return 0;
 }

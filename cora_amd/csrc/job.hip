@@ -207,8 +207,10 @@ void reserve_job_arena(cora_hip_job *job, int world, bool keep_own)
     const size_t room = share > 1 ? (total_b - ((size_t)24 << 30)) / share - ((size_t)6 << 30) : free_b - ((size_t)16 << 30);
     if (share > 1 && (room > free_b || room < ((size_t)8 << 30))) return;
     if (want > room) want = room;
+    const auto a0 = std::chrono::steady_clock::now();
     const bool ok = job->pool.reserve_arena(want);
     if (ok) job->arena_world = world;
+    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] arena: hipMalloc took %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
     if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] arena of %.1f GB (%d rank(s)): %s\n", want / 1073741824.0, world, ok ? "reserved" : "not available, separate blocks");
 }
 
@@ -270,6 +272,12 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
             if (trace) fprintf(stderr, "[cora] warm: packed-reference landing area pinned after %.1f ms\n", since());
             if (!job->h_stream.reserve(est)) (void)touch(job->h_stream.p, est);
             if (trace) fprintf(stderr, "[cora] warm: byte-stream landing area pinned after %.1f ms\n", since());
+            // the landing areas of the lists the host finishes (tied targets): one list per 2048 bases and one item per 512 are
+            // four times what the GRCh38-like workload needs; pinned here, st_items_finish finds them ready (2-3 ms of hipHostMalloc each)
+            const size_t lists = (size_t)(job->genome_bases / 2048) + 1024, items = (size_t)(job->genome_bases / 512) + 4096;
+            (void)job->h_hnodes.reserve(lists); (void)job->h_node_start.reserve(lists + 1);
+            (void)job->h_key.reserve(items); (void)job->h_meta.reserve(items); (void)job->h_blen.reserve(items);
+            if (trace) fprintf(stderr, "[cora] warm: host-list landing areas pinned after %.1f ms\n", since());
             table.join();
         });
     } else {

@@ -24,6 +24,12 @@ del contigs
 fa = os.path.join(tmp, "ref.fa")
 bench.write_fasta_image(fa, image, geom, names, W)
 del image
+if os.environ.get("E2E_TINY_FIRST"):          # does a run of the executable on a 250 kbp reference make the first big run fast?
+    g = os.path.join(ROOT, "tests", "golden", "inputs")
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "cora_amd", "bin", "homTable_setup"), os.path.join(g, "syn.fa"), "50", os.path.join(S, "phys_10.txt"),
+                        os.path.join(tmp, "tE"), os.path.join(tmp, "tI"), os.path.join(S, "par_8.txt"), "BOTH", "2", "FULL"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    print("tiny run first: exit %d, wall %.3f s" % (r.returncode, time.time() - t0), flush=True)
 for i, var in enumerate(variants):
     e, x = os.path.join(tmp, "E"), os.path.join(tmp, "I")
     for p in (e, x):
