@@ -376,12 +376,12 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         };
         if (!per_seed) {
             for (int q = 0; q < dp.nseeds; q++) RCQ(make(q));
-            launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs);
+            launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, -1, seed_first_digit_shift());
         }
         for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
             if (per_seed) {
                 RCQ(make(seed - 1));
-                launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, seed - 1);
+                launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, seed - 1, seed_first_digit_shift());
             }
             RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, sk.b[seed - 1], sk.c[seed - 1], nullptr, b_chain));
             codes[seed - 1].release(); hists[seed - 1].release(); skb[seed - 1].release(); skc[seed - 1].release();

@@ -322,7 +322,13 @@ int st_pack(cora_hip_job *job);
 int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out);
 int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from = nullptr);
 inline int exact_sort_bits(const cora_hip_job *job) { return job->hash_bits ? job->hash_bits : 40; }     // the exact sort runs on the top bits of the hash
-inline int seed_sort_lo(bool with_sketch) { return with_sketch ? 96 : 32; }                             // a seed record's code: 32 bits from here
+// The seed sorts leave the last code byte to the candidate kernels, which order every bucket of equal top 24 bits in LDS
+// (kernels.hip, "the last sort digit in LDS"): three global passes instead of four.  CORA_SEED_LDS=0: four passes, as before round 3.
+inline bool seed_lds_finish() { static const bool on = !(getenv("CORA_SEED_LDS") && atoi(getenv("CORA_SEED_LDS")) == 0); return on; }
+inline int seed_code_lo(bool with_sketch) { return with_sketch ? 96 : 32; }                             // a seed record's code: 32 bits from here
+inline int seed_sort_lo(bool with_sketch) { return seed_code_lo(with_sketch) + (seed_lds_finish() ? 8 : 0); }   // the bits its sort runs on start here
+inline int seed_sort_hi(bool with_sketch) { return seed_code_lo(with_sketch) + 32; }
+inline int seed_first_digit_shift() { return seed_lds_finish() ? 8 : 0; }                               // ... as a shift of the code (k_seed_codes_all's histograms)
 int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p);
 int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &host_ms);
 int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBuf<u32> &reps, u64 &n_out);

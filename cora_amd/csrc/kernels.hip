@@ -1043,7 +1043,8 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ reps, u64 n_reps,
                                                         u64 *__restrict__ out0, u64 *__restrict__ out1, u64 *__restrict__ out2,
                                                         u64 *__restrict__ out3, u32 *__restrict__ hist0, u32 *__restrict__ hist1,
-                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3, SeedSketches sk, int per_thread, int only)
+                                                        u32 *__restrict__ hist2, u32 *__restrict__ hist3, SeedSketches sk, int per_thread, int only,
+                                                        int hist_shift /* the first sort digit: code bits hist_shift .. + 7 */)
 {
     __shared__ u32 h[NS][256];
     const int tid = threadIdx.x;
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
                 const bool fwd = fwc[s] <= rcc[s];
                 const u32 c = fwd ? fwc[s] : rcc[s];
                 outs[s][r] = ((u64)c << 32) | g;
-                atomicAdd(&h[s][c & 255u], 1u);
+                atomicAdd(&h[s][(c >> hist_shift) & 255u], 1u);
                 if (sk.on) {                                       // (an array that is not wanted is null: the sharded flow moves b only)
                     const u32 o1 = fwd ? fwc[(s + 1) % NS] : rcc[(s + 1) % NS];
                     if (NS == 2) { if (sk.c[s]) sk.c[s][r] = o1; }
@@ -1524,6 +1525,495 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
             blk_slots[tile] = total;
             blk_staged[tile] = keep_all ? 1 : 0;
             blk_cand[tile] = (u64)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the last sort digit in LDS ("PS": partial sort)
+// Round 3.  The seed sort was four global passes over 16-byte records: 1.1 TB of the build's 2.7 TB, and its scatter runs at
+// 0.9 of a copy, so only fewer bytes make it faster.  In PS mode the records arrive sorted on the TOP 24 BITS of the code only
+// (three passes), stable: a "bucket" (equal code >> 8; 170 records on average at 2.9e9 records, 340 for the smallest codes,
+// since canonical codes crowd the low end) holds its records in position order with the low code byte unsorted.  The candidate
+// kernels finish the sort where the records pass through LDS anyway: every bucket is ordered by its last byte by ONE wave -- the
+// records go to registers, ranks come from the ballot match of the scatter kernel (rs_scatter) and a 256-counter histogram in
+// the wave's strip of LDS, and they are written back to the bucket's own slots, in place.  What is in LDS afterwards is what
+// the four-pass sort would have left there, and the pair logic above runs on it unchanged.
+//
+// Tiles.  A bucket must lie in ONE tile, so tiles are cut at bucket heads: with head(i) = record i opens a bucket (or i = 0, or
+// i = n), C(x) = the first head in [x, x + PS_OVER], else x itself; tile t owns the records [C(t T), C((t + 1) T)).  Both ends
+// depend on the records near them only, so neighbouring tiles agree.  LDS holds records t T - 1 .. t T + T + PS_OVER.  A cut that
+// falls INSIDE a bucket (no head within PS_OVER records: a repeat family whose copies share the seed's first 12 bases) makes the
+// tile that begins there "irregular"; so does a bucket of more than PS_MAXB records.  Irregular tiles are the walk's
+// (k_candidates_ps): every record there meets the earlier records of its BUCKET, in LDS and on into global memory, and takes the ones with
+// its own code -- in a bucket that large most have.  Palindromic codes (other slot kinds, Q1) are the walk's as well, but record by record:
+// the balanced kernel skips such records and says so (blk_mode bit 1), the walk then visits only those in that tile.  A tile can
+// therefore have slots from both kernels; the walk's counts live at index n_tiles + tile of every per-tile array.
+constexpr int PS_TILE = 1792;
+constexpr int PS_OVER = 510;
+constexpr int PS_R = PS_TILE + PS_OVER + 2;          // 2304 LDS slots of the balanced kernel: slot k + 1 = record base + k
+constexpr int PS_PER = PS_R / 256;                   // 9 slots per thread
+constexpr int PS_WAVE = PS_R / 4;                    // 576 per wave
+constexpr int PS_MAXB = 512;                         // a bucket is sorted in at most 8 rounds of 64
+constexpr int PS_WHALO = 256;                        // the walk keeps that many records before the tile as well
+constexpr int PS_WR = PS_WHALO + PS_TILE + PS_OVER + 2;      // 2560 slots: slot k + PS_WHALO = record base + k
+static_assert(PS_R % 256 == 0 && PS_WR % 256 == 0 && PS_R % 64 == 0, "tile geometry");
+
+__device__ __forceinline__ u32 ps_bucket(u64 key) { return (u32)(key >> 40); }
+
+// Bit s of heads[] = "the record in slot s opens a bucket" for the slots of one wave round; rec = record index of the slot.
+// A slot whose predecessor is not in LDS (slot 0) reports no head: it is never asked about.
+__device__ __forceinline__ bool ps_is_head(const u64 *s_key, int slot, long long rec, u64 n)
+{
+    if (rec < 0 || (u64)rec > n) return false;
+    if (rec == 0 || (u64)rec == n) return true;
+    if (slot == 0) return false;
+    return ps_bucket(s_key[slot]) != ps_bucket(s_key[slot - 1]);
+}
+
+// first set bit of the mask words in slots [sa, sb] (inclusive), or -1; uniform over the wave (broadcast LDS reads)
+__device__ __forceinline__ int ps_first_head(const u64 *heads, int sa, int sb)
+{
+    if (sa > sb) return -1;
+    int w = sa >> 6;
+    u64 m = heads[w] & (~0ull << (sa & 63));
+    for (;;) {
+        if (m) { const int at = (w << 6) + __ffsll((long long)m) - 1; return at <= sb ? at : -1; }
+        w++;
+        if ((w << 6) > sb) return -1;
+        m = heads[w];
+    }
+}
+
+// The owned slot range [f, e) of a tile whose LDS copy starts HB records before `base`; cut_mid = the tile starts inside a bucket.
+template <int HB>
+__device__ __forceinline__ void ps_cuts(const u64 *heads, u64 base, u64 n, int &f, int &e, bool &cut_mid)
+{
+    const int sb = HB;                                                  // slot of record `base`
+    const u64 xe = base + PS_TILE < n ? base + PS_TILE : n;
+    const int se = sb + (int)(xe - base);
+    const int lim_f = (int)((base + PS_OVER < n ? base + PS_OVER : n) - base) + sb;
+    const int lim_e = (int)((xe + PS_OVER < n ? xe + PS_OVER : n) - base) + sb;
+    const int hf = ps_first_head(heads, sb, lim_f), he = ps_first_head(heads, se, lim_e);
+    cut_mid = hf < 0;
+    f = hf < 0 ? sb : hf;
+    e = he < 0 ? se : he;
+}
+
+// One wave groups the bucket in slots [h, h + B) (2 <= B <= PS_MAXB) by the low code byte, in place: records to registers,
+// a 256-counter histogram in `hist` (the wave's 512 bytes: 16-bit counters, two to a word) filled by LDS atomics whose
+// return value is the record's rank among the records of its byte, the histogram's scan, and back.  Every lane of the wave
+// must call it with the same h, B.
+// Order INSIDE a run of equal codes: records of different rounds keep their order; records of one round (64 consecutive
+// slots) land in the order in which LDS serialises the atomics of one instruction.  Nothing here depends on that order: the pair
+// kernels name the later position k-mer 1 by comparing the two positions (HTS:2753-2762: k-mer 1 is the genomically later one),
+// every pair of a run is met exactly once whatever the order, and the order of the slots is of no consequence downstream
+// (items are sorted; ties are settled from the items themselves).  The first version ranked by ballot match, as rs_scatter
+// does (stable): 400 wave instructions per bucket, and the balanced kernel went from 18 to 39 ms -- issue-bound; this one takes 80.
+// What is written back is (rank << 32) | position: a record's rank among the EARLIER records of its code is all the pair logic
+// wants of the code from here on (the members of a run sit in rank order, so a record's partners are the `rank` slots before it).
+// Records with a palindromic code get rank 0 -- their pairs are the walk's (HTS:2769-2792) -- and are reported by the return value.
+template <bool SKB, bool SKC>
+__device__ __forceinline__ bool ps_sort_bucket(u64 *s_key, u64 *s_b, u32 *s_c, u32 *hist /* [128] */, int h, int B, int lane)
+{
+    constexpr int RMAX = PS_MAXB / 64;
+    u64 ka[RMAX], kb[SKB ? RMAX : 1];
+    u32 kc[SKC ? RMAX : 1], rk[RMAX];
+    bool any_pal = false;
+    hist[lane] = 0u; hist[64 + lane] = 0u;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        if (r * 64 < B) {
+            const int i = r * 64 + lane;
+            const bool in = i < B;
+            ka[r] = in ? s_key[h + i] : 0ull;
+            if (SKB) kb[r] = in ? s_b[h + i] : 0ull;
+            if (SKC) kc[r] = in ? s_c[h + i] : 0u;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        if (r * 64 < B) {
+            rk[r] = 0;
+            if (r * 64 + lane < B) {
+                const u32 d = (u32)(ka[r] >> 32) & 255u, sh = (d & 1u) * 16u;
+                rk[r] = (atomicAdd(&hist[d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // exclusive scan of the 256 counters: lane l owns digits 4 l .. 4 l + 3 (words 2 l, 2 l + 1)
+    {
+        const u32 w0 = hist[2 * lane], w1 = hist[2 * lane + 1];
+        const u32 c0 = w0 & 0xFFFFu, c1 = w0 >> 16, c2 = w1 & 0xFFFFu, c3 = w1 >> 16;
+        const u32 sum = c0 + c1 + c2 + c3;
+        const u32 ex = wave_scan_add(sum) - sum;
+        __builtin_amdgcn_wave_barrier();
+        hist[2 * lane] = ex | ((ex + c0) << 16);
+        hist[2 * lane + 1] = (ex + c0 + c1) | ((ex + c0 + c1 + c2) << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        if (r * 64 < B) {
+            if (r * 64 + lane < B) {
+                const u32 code = (u32)(ka[r] >> 32), d = code & 255u;
+                const int dst = h + (int)((hist[d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu) + (int)rk[r];
+                const bool pal = rc_code(code) == code;
+                any_pal |= pal;
+                s_key[dst] = ((u64)(pal ? 0u : rk[r]) << 32) | (u32)ka[r];
+                if (SKB) s_b[dst] = kb[r];
+                if (SKC) s_c[dst] = kc[r];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return any_pal;
+}
+
+// k_candidates_pairs on records sorted on the top 24 code bits (see above).  cnt_slots / blk_* / staged are indexed by tile.
+// blk_mode (counting pass writes it): 0 the walk does the whole tile, 1 done here, 3 done here except its palindromic records.
+template <bool WRITE, bool SKB, bool SKC>
+__global__ __launch_bounds__(256) void k_candidates_pairs_ps(DevParams p, const u64 *__restrict__ codes, u64 n, u32 *__restrict__ cnt_slots,
+                                                             u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
+                                                             PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c,
+                                                             u64 *__restrict__ staged, u8 *__restrict__ blk_staged, u8 *__restrict__ blk_mode,
+                                                             const u32 *__restrict__ tiles)
+{
+    const u32 tile = tiles ? tiles[blockIdx.x] : blockIdx.x;
+    __shared__ u64 s_key[PS_R];
+    __shared__ u64 s_b[SKB ? PS_R : 1];
+    __shared__ u32 s_c[SKC ? PS_R : 1];
+    __shared__ u32 s_mk[4][VP_STRIP];                // per wave: the histogram of the bucket sort, then the pair strip
+    __shared__ u64 s_heads[PS_R / 64];
+    __shared__ u32 s_val[WRITE ? 1 : VT_QUOTA];
+    __shared__ uint16_t s_own[WRITE ? 1 : VT_QUOTA];
+    __shared__ u32 s_seg[4], s_w[4];
+    __shared__ u32 s_n;
+    __shared__ u32 s_flag[2];                        // a bucket above PS_MAXB records / a palindromic code in the tile
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 base = (u64)tile * PS_TILE;
+    if (WRITE) {
+        if (!(blk_mode[tile] & 1) || blk_slots[tile] == 0 || blk_staged[tile]) return;
+    }
+    if (!WRITE && tid == 0) s_n = 0;
+    {
+        u64 rk[PS_PER], rb[SKB ? PS_PER : 1];
+        u32 rc[SKC ? PS_PER : 1];
+#pragma unroll
+        for (int q = 0; q < PS_PER; q++) {
+            const long long g = (long long)base - 1 + (q * 256 + tid);
+            const bool in = g >= 0 && (u64)g < n;
+            rk[q] = in ? __builtin_nontemporal_load(codes + g) : 0ull;
+            if (SKB) rb[q] = in ? __builtin_nontemporal_load(sk_b + g) : 0ull;
+            if (SKC) rc[q] = in ? __builtin_nontemporal_load(sk_c + g) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < PS_PER; q++) {
+            const int slot = q * 256 + tid;
+            s_key[slot] = rk[q];
+            if (SKB) s_b[slot] = rb[q];
+            if (SKC) s_c[slot] = rc[q];
+        }
+    }
+    __syncthreads();
+    // ---- bucket heads of all slots, the tile's cuts ----
+    if (base >= 1 && base - 1 + PS_R <= n) {
+        // every slot holds a record and none is the list's first or last: a slot opens a bucket iff its bucket differs from the one
+        // before it -- the lane before (one DPP shift), for lane 0 the last lane of the round before
+        u32 before = wv ? ps_bucket(s_key[wv * PS_WAVE - 1]) : ps_bucket(s_key[0]);       // (slot 0 is never asked about)
+#pragma unroll
+        for (int r = 0; r < PS_WAVE / 64; r++) {
+            const int slot = wv * PS_WAVE + r * 64 + lane;
+            const u32 bk = ps_bucket(s_key[slot]);
+            const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)before, (int)bk, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            const u64 bal = __ballot(bk != prev);
+            if (lane == 0) s_heads[slot >> 6] = bal;
+            before = (u32)__builtin_amdgcn_readlane((int)bk, 63);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < PS_WAVE / 64; r++) {
+            const int slot = wv * PS_WAVE + r * 64 + lane;
+            const u64 bal = __ballot(ps_is_head(s_key, slot, (long long)base - 1 + slot, n));
+            if (lane == 0) s_heads[slot >> 6] = bal;
+        }
+    }
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+    __syncthreads();
+    int f, e;
+    bool cut_mid;
+    ps_cuts<1>(s_heads, base, n, f, e, cut_mid);
+    if (cut_mid) {                                                   // (uniform) the tile begins inside a bucket: the walk's
+        if (!WRITE && tid == 0) { blk_mode[tile] = 0; blk_slots[tile] = 0; blk_staged[tile] = 0; blk_cand[tile] = 0; }
+        return;
+    }
+    // ---- every bucket of the owned range grouped by its last code byte, by the wave its head falls to; ranks into the keys ----
+    {
+        const int lo_w = f > wv * PS_WAVE ? f : wv * PS_WAVE, hi_w = e < (wv + 1) * PS_WAVE ? e : (wv + 1) * PS_WAVE;
+        bool any_pal = false, too_big = false;
+        int h = ps_first_head(s_heads, lo_w, hi_w - 1);
+        while (h >= 0) {
+            int h2 = ps_first_head(s_heads, h + 1, e - 1);
+            const int end = h2 < 0 ? e : h2;
+            const int B = end - h;
+            if (B > PS_MAXB) too_big = true;
+            else if (B > 1) any_pal |= ps_sort_bucket<SKB, SKC>(s_key, s_b, s_c, s_mk[wv], h, B, lane);
+            else if (lane == 0) {                                   // a bucket of one: rank 0
+                const u64 k1 = s_key[h];
+                any_pal |= rc_code((u32)(k1 >> 32)) == (u32)(k1 >> 32);
+                s_key[h] = (u64)(u32)k1;
+            }
+            h = (h2 >= 0 && h2 < hi_w) ? h2 : -1;
+        }
+        if (too_big) s_flag[0] = 1;                                  // (every writer writes the same value)
+        if (any_pal) s_flag[1] = 1;
+    }
+    __syncthreads();
+    if (s_flag[0]) {                                                 // a bucket too large to group here: the walk's
+        if (!WRITE && tid == 0) { blk_mode[tile] = 0; blk_slots[tile] = 0; blk_staged[tile] = 0; blk_cand[tile] = 0; }
+        return;
+    }
+    const bool has_pal = s_flag[1] != 0;
+    // ---- run ranks, as the grouping left them: lane l of wave w owns the PS_PER slots from f + PS_WAVE w + PS_PER l ----
+    const int seg0 = f + PS_WAVE * wv;
+    const int slot0 = seg0 + PS_PER * lane;
+    u32 r[PS_PER];
+    u32 lane_sum = 0;
+#pragma unroll
+    for (int j = 0; j < PS_PER; j++) {
+        const int sl = slot0 + j;
+        r[j] = sl < e ? (u32)(s_key[sl] >> 32) : 0u;
+        lane_sum += r[j];
+    }
+    // ---- pairs of the wave, 64 at a time (as k_candidates_pairs) ----
+    const u32 P = wave_scan_add(lane_sum);
+    const u32 W = (u32)__builtin_amdgcn_readlane((int)P, 63);
+    u32 pr[PS_PER];
+    {
+        u32 x = P - lane_sum;
+#pragma unroll
+        for (int j = 0; j < PS_PER; j++) { pr[j] = x; x += r[j]; }
+    }
+    u32 seg_pre = 0;
+    if (WRITE) for (int w = 0; w < wv; w++) seg_pre += cnt_slots[(u64)tile * 256 + w];
+    const u64 at0 = WRITE ? blk_off[tile] + seg_pre : 0;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    u32 wslots = 0, carry_o = 0, carry_P = 0;
+    bool spill = false;
+    u32 *mk = s_mk[wv];
+    for (u32 c0 = 0; c0 < W; c0 += VP_STRIP) {
+#pragma unroll
+        for (int x = 0; x < VP_STRIP / 64; x++) mk[x * 64 + lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < PS_PER; j++)
+            if (r[j] && pr[j] >= c0 && pr[j] < c0 + VP_STRIP) mk[pr[j] - c0] = ((u32)(PS_PER * lane + j + 1) << 16) | (pr[j] - c0);
+        __builtin_amdgcn_wave_barrier();
+        for (u32 t = 0; t < VP_STRIP && c0 + t < W; t += 64) {
+            const u32 q = c0 + t + lane;
+            const u32 v = wave_scan_max(mk[t + lane]);
+            const u32 o_rec = v ? (v >> 16) - 1u : carry_o;
+            const u32 o_P = v ? c0 + (v & 0xFFFFu) : carry_P;
+            carry_o = (u32)__builtin_amdgcn_readlane((int)o_rec, 63); carry_P = (u32)__builtin_amdgcn_readlane((int)o_P, 63);
+            bool pass = false;
+            int li = 0, lj = 0;
+            if (q < W) {
+                li = seg0 + (int)o_rec;
+                lj = li - (int)(q - o_P + 1u);
+                int mm = 0;
+                if (SKB) { const u64 x = s_b[li] ^ s_b[lj]; mm += __popcll((x | (x >> 1)) & M55); }
+                if (SKC) { const u32 y = s_c[li] ^ s_c[lj]; mm += __popc((y | (y >> 1)) & 0x55555555u); }
+                pass = mm <= p.d;
+            }
+            const u64 bal = __ballot(pass);
+            if (pass) {
+                const u32 rank = wslots + (u32)__popcll(bal & lt_mask);
+                if (WRITE) {
+                    PairRec rec;                                       // (k-mer 1 = the later position: ps_sort_bucket)
+                    const u32 ga = (u32)s_key[li], gb = (u32)s_key[lj];
+                    rec.p1 = ga > gb ? ga : gb; rec.p2 = ga > gb ? gb : ga; rec.meta = SLOT_PLAIN;
+                    slots[at0 + rank] = rec;
+                } else {
+                    const u32 en = rank < 4096u ? atomicAdd(&s_n, 1u) : (u32)VT_QUOTA;
+                    if (en < (u32)VT_QUOTA) { s_val[WRITE ? 0 : en] = ((u32)li << 16) | (u32)lj; s_own[WRITE ? 0 : en] = (uint16_t)((wv << 12) | rank); }
+                    else spill = true;
+                }
+            }
+            wslots += (u32)__popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!WRITE) {
+        if (lane == 0) { s_seg[wv] = wslots; s_w[wv] = W; }
+        const bool keep = !__syncthreads_or(spill);
+        const u32 total = s_seg[0] + s_seg[1] + s_seg[2] + s_seg[3];
+        const bool keep_all = keep && total <= (u32)VT_QUOTA;
+        if (keep_all) {
+            if ((u32)tid < total) {
+                const u32 en = s_val[WRITE ? 0 : tid], o = s_own[WRITE ? 0 : tid];
+                u32 pre = 0;
+                for (u32 w = 0; w < (o >> 12); w++) pre += s_seg[w];
+                const u32 ga = (u32)s_key[en >> 16], gb = (u32)s_key[en & 0xFFFFu];
+                staged[(u64)tile * VT_QUOTA + pre + (o & 4095u)] = ga > gb ? ((u64)ga << 32) | gb : ((u64)gb << 32) | ga;
+            }
+        } else if (tid < 4) cnt_slots[(u64)tile * 256 + tid] = s_seg[tid];
+        if (tid == 0) {
+            blk_mode[tile] = has_pal ? 3 : 1;
+            blk_slots[tile] = total;
+            blk_staged[tile] = keep_all ? 1 : 0;
+            blk_cand[tile] = (u64)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        }
+    }
+}
+
+// The walk in PS mode: the tiles the balanced kernel left whole (blk_mode 0) and, record by record, the palindromic codes of the
+// tiles it did (blk_mode 3).  A record meets the earlier records of its BUCKET -- LDS first, then global memory -- and takes
+// those with its own code (HTS:2753-2762; in a bucket too large for LDS most records carry the family's code).  The same tile
+// cuts as above.  Outputs at index n_tiles + tile.
+template <bool WRITE, bool SKB, bool SKC>
+__global__ __launch_bounds__(256) void k_candidates_ps(DevParams p, const u64 *__restrict__ codes, u64 n, u32 n_tiles, u32 *__restrict__ cnt_slots,
+                                                       u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
+                                                       PairRec *__restrict__ slots, const u64 *__restrict__ sk_b, const u32 *__restrict__ sk_c,
+                                                       u64 *__restrict__ staged, u8 *__restrict__ blk_staged, const u8 *__restrict__ blk_mode,
+                                                       const u32 *__restrict__ tiles)
+{
+    const u32 tile = tiles[blockIdx.x];
+    const u64 v = (u64)n_tiles + tile;
+    const u32 mode = blk_mode[tile];
+    if (mode == 1) return;                                           // (nothing here for the walk; such tiles are not listed)
+    const bool pal_only = mode != 0;
+    __shared__ u64 s_key[PS_WR];
+    __shared__ u64 s_b[SKB ? PS_WR : 1];
+    __shared__ u32 s_c[SKC ? PS_WR : 1];
+    __shared__ u64 s_heads[PS_WR / 64];
+    __shared__ u32 s_val[WRITE ? 1 : VT_QUOTA];
+    __shared__ uint16_t s_own[WRITE ? 1 : VT_QUOTA];
+    __shared__ u32 s_pre[WRITE ? 1 : 256];
+    __shared__ u32 s_n;
+    __shared__ u32 l4[4];
+    __shared__ u64 c4[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 base = (u64)tile * PS_TILE;
+    u64 at = 0;
+    u32 mine = 1;
+    bool spill = false;
+    if (!WRITE && tid == 0) s_n = 0;
+    if (WRITE) {
+        if (blk_slots[v] == 0 || blk_staged[v]) return;
+        mine = cnt_slots[v * 256 + tid];
+        at = blk_off[v] + block_excl_scan_u32(mine, l4, nullptr);
+    }
+    const long long rec0 = (long long)base - PS_WHALO;              // record of slot 0
+    const int first_slot = rec0 < 0 ? (int)-rec0 : 0;                // first slot that holds a record
+    {
+        constexpr int LD = PS_WR / 256;
+        u64 rk[LD], rb[SKB ? LD : 1];
+        u32 rc[SKC ? LD : 1];
+#pragma unroll
+        for (int q = 0; q < LD; q++) {
+            const long long g = rec0 + (q * 256 + tid);
+            const bool in = g >= 0 && (u64)g < n;
+            rk[q] = in ? __builtin_nontemporal_load(codes + g) : 0ull;
+            if (SKB) rb[q] = in ? __builtin_nontemporal_load(sk_b + g) : 0ull;
+            if (SKC) rc[q] = in ? __builtin_nontemporal_load(sk_c + g) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < LD; q++) {
+            const int slot = q * 256 + tid;
+            s_key[slot] = rk[q];
+            if (SKB) s_b[slot] = rb[q];
+            if (SKC) s_c[slot] = rc[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PS_WR / 256; r++) {
+        const int slot = wv * (PS_WR / 4) + r * 64 + lane;
+        const u64 bal = __ballot(ps_is_head(s_key, slot, rec0 + slot, n));
+        if (lane == 0) s_heads[slot >> 6] = bal;
+    }
+    __syncthreads();
+    int f, e;
+    bool cut_mid;
+    ps_cuts<PS_WHALO>(s_heads, base, n, f, e, cut_mid);
+    const bool have_sk = SKB || SKC;
+    u32 nslot = 0;
+    u64 ncand = 0;
+#pragma unroll 1
+    for (int k = 0; k < (mine ? PS_PER + 1 : 0); k++) {
+        const int li = f + k * 256 + tid;
+        if (li >= e) break;
+        const u64 ci = s_key[li];
+        const u32 code = (u32)(ci >> 32), gi = (u32)ci, bkt = ps_bucket(ci);
+        const bool pal = rc_code(code) == code;
+        if (pal_only && !pal) continue;
+        const bool filter = have_sk && !pal;
+        const u64 bi = (filter && SKB) ? s_b[li] : 0ull;
+        const u32 qi = (filter && SKC) ? s_c[li] : 0u;
+        u32 nc = 0;
+        if (pal) {
+            nc++;
+            if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gi; slots[at].meta = SLOT_PAL_SELF; at++; }
+            else { nslot++; spill = true; }
+        }
+        auto visit = [&](u32 gj, u64 bj, u32 qj, int lj) {
+            if (pal) {
+                nc += 4;
+                if (WRITE) for (u32 c = SLOT_PAL_FWD0; c <= SLOT_PAL_REV1; c++, at++) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = c; }
+                else nslot += 4;
+                return;
+            }
+            nc++;
+            if (filter) {
+                int mm = 0;
+                if (SKB) { const u64 x = bi ^ bj; mm += __popcll((x | (x >> 1)) & M55); }
+                if (SKC) { const u32 y = qi ^ qj; mm += __popc((y | (y >> 1)) & 0x55555555u); }
+                if (mm > p.d) return;
+            }
+            if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = SLOT_PLAIN; at++; }
+            else {
+                const u32 en = (lj >= 0 && nslot < 256u) ? atomicAdd(&s_n, 1u) : (u32)VT_QUOTA;
+                if (en < (u32)VT_QUOTA) { s_val[WRITE ? 0 : en] = ((u32)li << 16) | (u32)lj; s_own[WRITE ? 0 : en] = (uint16_t)((tid << 8) | nslot); }
+                else spill = true;
+                nslot++;
+            }
+        };
+        // the earlier records of the bucket: in LDS ...
+        int j = li - 1;
+        while (j >= first_slot && ps_bucket(s_key[j]) == bkt) {
+            if ((u32)(s_key[j] >> 32) == code) visit((u32)s_key[j], SKB ? s_b[j] : 0ull, SKC ? s_c[j] : 0u, j);
+            j--;
+        }
+        // ... and, when the bucket reaches the start of the LDS copy, on into global memory
+        if (j < first_slot && rec0 > 0) {
+            for (u64 g = (u64)rec0; g-- > 0;) {
+                const u64 cj = codes[g];
+                if (ps_bucket(cj) != bkt) break;
+                if ((u32)(cj >> 32) == code) visit((u32)cj, SKB ? sk_b[g] : 0ull, SKC ? sk_c[g] : 0u, -1);
+            }
+        }
+        ncand += nc;
+    }
+    if (!WRITE) {
+        u64 c = ncand;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((tid & 63) == 0) c4[tid >> 6] = c;
+        u32 total;
+        const u32 pre = block_excl_scan_u32(nslot, l4, &total);
+        s_pre[WRITE ? 0 : tid] = pre;
+        const bool keep_all = !__syncthreads_or(spill) && total <= (u32)VT_QUOTA;
+        if (keep_all) {
+            if ((u32)tid < total) {
+                const u32 en = s_val[WRITE ? 0 : tid], o = s_own[WRITE ? 0 : tid];
+                staged[v * VT_QUOTA + s_pre[WRITE ? 0 : (o >> 8)] + (o & 255u)] = ((u64)(u32)s_key[en >> 16] << 32) | (u32)s_key[en & 0xFFFFu];
+            }
+        } else cnt_slots[v * 256 + tid] = nslot;
+        if (tid == 0) {
+            blk_slots[v] = total;
+            blk_staged[v] = keep_all ? 1 : 0;
+            blk_cand[v] = c4[0] + c4[1] + c4[2] + c4[3];
         }
     }
 }
@@ -2329,15 +2819,15 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
     if (n_reps) hipLaunchKernelGGL(k_seed_codes, grid_for(n_reps), dim3(256), 0, s, p, pk, reps, n_reps, seed, out);
 }
 void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
-                           const SeedSketches &sk, u32 tile_records, int only)
+                           const SeedSketches &sk, u32 tile_records, int only, int hist_shift)
 {
     if (!n_reps) return;
     const dim3 g((unsigned)((n_reps + tile_records - 1) / tile_records));
     const int per_thread = (int)(tile_records / 256);
     switch (p.nseeds) {
-    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only); break;
-    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only); break;
-    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only); break;
+    case 2: hipLaunchKernelGGL(k_seed_codes_all<2>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only, hist_shift); break;
+    case 3: hipLaunchKernelGGL(k_seed_codes_all<3>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only, hist_shift); break;
+    default: hipLaunchKernelGGL(k_seed_codes_all<4>, g, dim3(256), 0, s, p, pk, reps, n_reps, out[0], out[1], out[2], out[3], hist[0], hist[1], hist[2], hist[3], sk, per_thread, only, hist_shift); break;
     }
 }
 u64 verify_blocks(u64 n) { return (n + VT_TILE - 1) / VT_TILE; }
@@ -2419,6 +2909,83 @@ void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes
     }
     launch_candidates<true>(s, true, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles_pairs, n_pairs);
     launch_candidates<true>(s, false, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles_walk, n_walk);
+}
+// ---- PS mode (records sorted on the top 24 code bits; k_candidates_pairs_ps / k_candidates_ps): per-tile arrays hold 2 x
+// verify_blocks_ps(n) entries, the balanced kernel's at [tile], the walk's at [tiles + tile] ----
+u64 verify_blocks_ps(u64 n) { return (n + PS_TILE - 1) / PS_TILE; }
+u64 verify_staging_elems_ps(u64 n) { return 2 * verify_blocks_ps(n) * VT_QUOTA; }
+
+// which = 0: the tiles the walk's counting pass has to visit (left whole, or holding palindromic codes); 1 / 2: the tiles whose
+// slots the write pass of the balanced kernel / of the walk has to produce
+__global__ __launch_bounds__(256) void k_tile_list_ps(u32 n_tiles, const u8 *__restrict__ blk_mode, const u32 *__restrict__ blk_slots,
+                                                      const u8 *__restrict__ blk_staged, int which, u32 *__restrict__ list, u32 *__restrict__ count)
+{
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    bool want = false;
+    if (t < n_tiles) {
+        const u32 mode = blk_mode[t];
+        if (which == 0) want = mode != 1;
+        else if (which == 1) want = (mode & 1) && blk_slots[t] != 0 && !blk_staged[t];
+        else want = mode != 1 && blk_slots[n_tiles + t] != 0 && !blk_staged[n_tiles + t];
+    }
+    const u64 bal = __ballot(want);
+    if (!bal) return;
+    const int lane = threadIdx.x & 63;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(count, (u32)__popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (want) list[base + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = t;
+}
+void launch_tile_list_ps(hipStream_t s, u64 n_tiles, const u8 *blk_mode, const u32 *blk_slots, const u8 *blk_staged, int which, u32 *list, u32 *count)
+{
+    if (n_tiles) hipLaunchKernelGGL(k_tile_list_ps, grid_for(n_tiles), dim3(256), 0, s, (u32)n_tiles, blk_mode, blk_slots, blk_staged, which, list, count);
+}
+
+template <bool WRITE>
+static void launch_pairs_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand, const u64 *blk_off,
+                            PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode, const u32 *tiles, u32 n_listed)
+{
+    if (!n || (tiles && !n_listed)) return;
+    const dim3 g(tiles ? n_listed : (unsigned)verify_blocks_ps(n)), b(256);
+#define CAND_ARGS p, codes, n, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles
+    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates_pairs_ps<WRITE, true, true>), g, b, 0, s, CAND_ARGS);
+    else if (sk_b) hipLaunchKernelGGL((k_candidates_pairs_ps<WRITE, true, false>), g, b, 0, s, CAND_ARGS);
+    else if (sk_c) hipLaunchKernelGGL((k_candidates_pairs_ps<WRITE, false, true>), g, b, 0, s, CAND_ARGS);
+    else hipLaunchKernelGGL((k_candidates_pairs_ps<WRITE, false, false>), g, b, 0, s, CAND_ARGS);
+#undef CAND_ARGS
+}
+template <bool WRITE>
+static void launch_walk_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand, const u64 *blk_off,
+                           PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, const u8 *blk_mode, const u32 *tiles, u32 n_listed)
+{
+    if (!n || !n_listed) return;
+    const dim3 g(n_listed), b(256);
+    const u32 nt = (u32)verify_blocks_ps(n);
+#define CAND_ARGS p, codes, n, nt, cnt_slots, blk_slots, blk_cand, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles
+    if (sk_b && sk_c) hipLaunchKernelGGL((k_candidates_ps<WRITE, true, true>), g, b, 0, s, CAND_ARGS);
+    else if (sk_b) hipLaunchKernelGGL((k_candidates_ps<WRITE, true, false>), g, b, 0, s, CAND_ARGS);
+    else if (sk_c) hipLaunchKernelGGL((k_candidates_ps<WRITE, false, true>), g, b, 0, s, CAND_ARGS);
+    else hipLaunchKernelGGL((k_candidates_ps<WRITE, false, false>), g, b, 0, s, CAND_ARGS);
+#undef CAND_ARGS
+}
+void launch_candidates_count_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                                const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode)
+{
+    launch_pairs_ps<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged, blk_mode, nullptr, 0);
+}
+void launch_candidates_walk_count_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                                     const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, const u8 *blk_mode, const u32 *tiles, u32 n_listed)
+{
+    launch_walk_ps<false>(s, p, codes, n, cnt_slots, blk_slots, blk_cand, nullptr, nullptr, sk_b, sk_c, staged, blk_staged, blk_mode, tiles, n_listed);
+}
+void launch_candidates_write_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, const u64 *blk_off,
+                                PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode,
+                                const u32 *tiles_pairs, u32 n_pairs, const u32 *tiles_walk, u32 n_walk)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_staged_slots, dim3((unsigned)(2 * verify_blocks_ps(n))), dim3(VT_QUOTA), 0, s, staged, blk_slots, blk_staged, blk_off, slots);
+    launch_pairs_ps<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles_pairs, n_pairs);
+    launch_walk_ps<true>(s, p, codes, n, cnt_slots, blk_slots, nullptr, blk_off, slots, sk_b, sk_c, staged, blk_staged, blk_mode, tiles_walk, n_walk);
 }
 void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid)
 {

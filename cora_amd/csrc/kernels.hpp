@@ -100,7 +100,8 @@ void launch_seed_codes(hipStream_t s, const DevParams &p, const u64 *pk, const u
 struct SeedSketches { int on; u64 *b[4]; u32 *c[4]; };
 void launch_seed_codes_all(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *reps, u64 n_reps, u64 *const out[4], u32 *const hist[4],
                            const SeedSketches &sk, u32 tile_records /* radix_sort_tile_records() of the record shape */,
-                           int only = -1 /* >= 0: write this (0-based) seed's arrays only */);
+                           int only = -1 /* >= 0: write this (0-based) seed's arrays only */,
+                           int hist_shift = 0 /* the digit the tile histograms count: code bits hist_shift .. + 7 (8 when the sort leaves the last byte to LDS) */);
 // Pair verification over the n code-sorted records of one seed (kernels.hip: k_candidates, k_judge, k_slot_compact).
 // candidates: one workgroup per tile of records; cnt_slots[verify_blocks(n) * 256] per thread, blk_slots / blk_cand per
 // workgroup; sk_*: the sketches, sorted with the codes, or null.  judge: slots -> pair records or none, in place, and
@@ -121,6 +122,19 @@ void launch_candidates_write(hipStream_t s, const DevParams &p, const u64 *codes
 // list[0 .. *count) = the tiles a candidate pass has to look at (which: 0 left to the walk, 1 / 2 write pass of the balanced kernel /
 // of the walk); *count (device) must be zero
 void launch_tile_list(hipStream_t s, u64 n_tiles, const u8 *blk_mode, const u32 *blk_slots, const u8 *blk_staged, int which, u32 *list, u32 *count);
+// The same three passes over records sorted on the TOP 24 BITS of the code only (kernels.hip, "the last sort digit in LDS"): tiles
+// cut at bucket heads, every bucket ordered in LDS first.  All per-tile arrays hold 2 x verify_blocks_ps(n) entries (the balanced
+// kernel's, then the walk's); cnt_slots 2 x verify_blocks_ps(n) x 256; blk_slots / blk_cand / blk_staged must be zero on entry.
+u64 verify_blocks_ps(u64 n);
+u64 verify_staging_elems_ps(u64 n);
+void launch_candidates_count_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                                const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode);
+void launch_candidates_walk_count_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, u64 *blk_cand,
+                                     const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, const u8 *blk_mode, const u32 *tiles, u32 n_listed);
+void launch_candidates_write_ps(hipStream_t s, const DevParams &p, const u64 *codes, u64 n, u32 *cnt_slots, u32 *blk_slots, const u64 *blk_off,
+                                PairRec *slots, const u64 *sk_b, const u32 *sk_c, u64 *staged, u8 *blk_staged, u8 *blk_mode,
+                                const u32 *tiles_pairs, u32 n_pairs, const u32 *tiles_walk, u32 n_walk);
+void launch_tile_list_ps(hipStream_t s, u64 n_tiles, const u8 *blk_mode, const u32 *blk_slots, const u8 *blk_staged, int which, u32 *list, u32 *count);
 void launch_judge(hipStream_t s, const DevParams &p, const u64 *pk, PairRec *slots, u64 n_slots, int seed, u32 *blk_valid /* [ceil(n_slots / 256)] */);
 void launch_slot_compact(hipStream_t s, const PairRec *slots, u64 n_slots, const u64 *blk_off, PairRec *pairs);
 void launch_sum_u64(hipStream_t s, const u64 *in, u64 n, u64 *out /* device, accumulated into */);

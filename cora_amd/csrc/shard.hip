@@ -311,9 +311,8 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
     case ST_VERIFY: {
         if (sh.filter) {
             const SortSource from = source_of(sh, 2, sh.seed_sketch, false);
-            const int lo = seed_sort_lo(sh.seed_sketch);
             u64 kept = 0;
-            if (radix_sort_count_kept(s, from, lo, lo + 32, job->sort_scratch, &kept)) return fail(100, "radix sort failed");
+            if (radix_sort_count_kept(s, from, seed_sort_lo(sh.seed_sketch), seed_sort_hi(sh.seed_sketch), job->sort_scratch, &kept)) return fail(100, "radix sort failed");
             if (kept) {
                 RCQ(sh.recv_a.alloc(kept));
                 // the sketches' second word climbs through a chain of arrays when the arena has the room (job.hip: why)

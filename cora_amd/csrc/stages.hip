@@ -256,42 +256,63 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     else if (sk_b) { RCQ(skb_tmp.alloc(n)); ck.b = sk_b; ct.b = skb_tmp.p; }               // the sketches travel with their records
     if (sk_c) { RCQ(skc_tmp.alloc(n)); ck.c = sk_c; ct.c = skc_tmp.p; }
     // the records are a (code << 32 | position); with a b array the sort's logical key is a:b, i.e. a's bits sit 64 higher
-    const int key_lo = seed_sort_lo(sk_b != nullptr), key_hi = key_lo + 32;
+    const int key_lo = seed_sort_lo(sk_b != nullptr), key_hi = seed_sort_hi(sk_b != nullptr);
     if (radix_sort(s, ck, ct, n, key_lo, key_hi, job->sort_scratch, &job->sort_timing, first_hist, from)) return fail(100, "radix sort failed");
-    const u64 ab = verify_blocks(n);                             // workgroups (tiles) of the candidate kernels
+    const bool lds = seed_lds_finish();                           // the records are sorted on the top 24 code bits; the candidate kernels order the rest in LDS
+    const u64 ab = lds ? verify_blocks_ps(n) : verify_blocks(n);  // workgroups (tiles) of the candidate kernels
+    const u64 vt = lds ? 2 * ab : ab;                             // per-tile entries (PS: the balanced kernel's, then the walk's)
     u64 totals[2] = {0, 0};                                      // slots, comparisons
     DBuf<PairRec> slots;
     {
         DBuf<u32> cnt_slots, blk_slots;
         DBuf<u64> blk_cand, slot_off, scr_a, staged;
         DBuf<u8> blk_staged;
-        RCQ(cnt_slots.alloc(ab * 256)); RCQ(blk_slots.alloc(ab)); RCQ(blk_cand.alloc(ab));
-        RCQ(slot_off.alloc(ab)); RCQ(scr_a.alloc(scan_scratch_elems(ab)));
-        RCQ(staged.alloc(verify_staging_elems(n))); RCQ(blk_staged.alloc(ab));
+        RCQ(cnt_slots.alloc(vt * 256)); RCQ(blk_slots.alloc(vt)); RCQ(blk_cand.alloc(vt));
+        RCQ(slot_off.alloc(vt)); RCQ(scr_a.alloc(scan_scratch_elems(vt)));
+        RCQ(staged.alloc(lds ? verify_staging_elems_ps(n) : verify_staging_elems(n))); RCQ(blk_staged.alloc(vt));
         DBuf<u8> blk_mode;
-        static const bool pairs_kernel = !(getenv("CORA_PAIRS") && atoi(getenv("CORA_PAIRS")) == 0);      // (0: the walk does every tile)
-        if (pairs_kernel) RCQ(blk_mode.alloc(ab));
-        launch_candidates_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p);
-        // the passes that have work in few tiles only take those tiles as lists: [0] the tiles left to the walk, [1] / [2] the
-        // tiles whose slots the write pass of the balanced kernel / of the walk must produce
+        static const bool pairs_kernel = !(getenv("CORA_PAIRS") && atoi(getenv("CORA_PAIRS")) == 0);      // (0: the walk does every tile; four-pass mode only)
+        if (pairs_kernel || lds) RCQ(blk_mode.alloc(ab));
         DBuf<u32> tile_list[3], list_n;
         u32 n_listed[3] = {0, 0, 0};
-        if (pairs_kernel) {
+        if (lds) {
+            // (the walk writes its half of the per-tile arrays for the tiles it visits only)
+            HIPQ(hipMemsetAsync(blk_slots.p + ab, 0, ab * sizeof(u32), s));
+            HIPQ(hipMemsetAsync(blk_cand.p + ab, 0, ab * sizeof(u64), s));
+            HIPQ(hipMemsetAsync(blk_staged.p + ab, 0, ab, s));
+            launch_candidates_count_ps(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p);
             for (auto &l : tile_list) RCQ(l.alloc(ab));
             RCQ(list_n.alloc(3));
             HIPQ(hipMemsetAsync(list_n.p, 0, 3 * sizeof(u32), s));
-            launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 0, tile_list[0].p, list_n.p);
+            launch_tile_list_ps(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 0, tile_list[0].p, list_n.p);
             HIPQ(hipMemcpyAsync(n_listed, list_n.p, sizeof(u32), hipMemcpyDeviceToHost, s));
             HIPQ(hipStreamSynchronize(s));
-            launch_candidates_walk_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
-                                         tile_list[0].p, n_listed[0]);
-            launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 1, tile_list[1].p, list_n.p + 1);
-            launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 2, tile_list[2].p, list_n.p + 2);
+            launch_candidates_walk_count_ps(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
+                                            tile_list[0].p, n_listed[0]);
+            launch_tile_list_ps(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 1, tile_list[1].p, list_n.p + 1);
+            launch_tile_list_ps(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 2, tile_list[2].p, list_n.p + 2);
             HIPQ(hipMemcpyAsync(n_listed, list_n.p, sizeof n_listed, hipMemcpyDeviceToHost, s));
+        } else {
+            launch_candidates_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p);
+            // the passes that have work in few tiles only take those tiles as lists: [0] the tiles left to the walk, [1] / [2] the
+            // tiles whose slots the write pass of the balanced kernel / of the walk must produce
+            if (pairs_kernel) {
+                for (auto &l : tile_list) RCQ(l.alloc(ab));
+                RCQ(list_n.alloc(3));
+                HIPQ(hipMemsetAsync(list_n.p, 0, 3 * sizeof(u32), s));
+                launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 0, tile_list[0].p, list_n.p);
+                HIPQ(hipMemcpyAsync(n_listed, list_n.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+                HIPQ(hipStreamSynchronize(s));
+                launch_candidates_walk_count(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, blk_cand.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
+                                             tile_list[0].p, n_listed[0]);
+                launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 1, tile_list[1].p, list_n.p + 1);
+                launch_tile_list(s, ab, blk_mode.p, blk_slots.p, blk_staged.p, 2, tile_list[2].p, list_n.p + 2);
+                HIPQ(hipMemcpyAsync(n_listed, list_n.p, sizeof n_listed, hipMemcpyDeviceToHost, s));
+            }
         }
-        if (exclusive_scan_u32_to_u64(s, blk_slots.p, slot_off.p, ab, scr_a.p, tots.p)) return fail(100, "scan launch failed");
+        if (exclusive_scan_u32_to_u64(s, blk_slots.p, slot_off.p, vt, scr_a.p, tots.p)) return fail(100, "scan launch failed");
         HIPQ(hipMemsetAsync(tots.p + 1, 0, sizeof(u64), s));
-        launch_sum_u64(s, blk_cand.p, ab, tots.p + 1);
+        launch_sum_u64(s, blk_cand.p, vt, tots.p + 1);
         HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
         HIPQ(hipStreamSynchronize(s));
         job->stats.candidate_pairs += totals[1];
@@ -299,8 +320,10 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
         if (sk_b || sk_c) job->stats.seed_sketch = 1;
         if (totals[0] == 0) { HIPQ(hipGetLastError()); return 0; }
         RCQ(slots.alloc(totals[0]));
-        launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
-                                tile_list[1].p, n_listed[1], tile_list[2].p, n_listed[2]);
+        if (lds) launch_candidates_write_ps(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
+                                           tile_list[1].p, n_listed[1], tile_list[2].p, n_listed[2]);
+        else launch_candidates_write(s, dp, ck.a, n, cnt_slots.p, blk_slots.p, slot_off.p, slots.p, ck.b, ck.c, staged.p, blk_staged.p, blk_mode.p,
+                                     tile_list[1].p, n_listed[1], tile_list[2].p, n_listed[2]);
     }
     const u64 n_slots = totals[0], jb = (n_slots + 255) / 256;
     DBuf<u32> blk_valid;
