@@ -188,6 +188,20 @@ def test_tables_match_reference_golden(name):
     assert i == helpers.read(os.path.join(want, "Inexact")), "%s: Inexact differs" % name
 
 
+@pytest.mark.parametrize("name", ["syn_k50_d2_p10t8", "pal_k50_d2", "lowcx_k64_d3", "fam_k48_d3", "ecoli_like_k50_d2"])
+def test_four_pass_seed_sort_is_still_there(name, tmp_path, monkeypatch):
+    """Round 3 moved the last byte of the seed sort into the candidate kernels (three global passes; kernels.hip, "the last sort digit
+    in LDS"), which every other test now runs.  CORA_SEED_LDS=0 keeps the four-pass sort with the round-2 candidate kernels (the A/B
+    switch of DESIGN.md section 4): same tables.  The switch is read once per process, hence the executable."""
+    c, want = helpers.golden_case(name)
+    exe = os.path.join(hip.BIN_DIR, "homTable_setup_L" if c["L"] else "homTable_setup")
+    monkeypatch.setenv("CORA_SEED_LDS", "0")
+    ex, inx, r = helpers.run_tool(exe, helpers.input_path(c["input"]), c["K"], c["d"], helpers.split_path("phys", c["p"]),
+                                  helpers.split_path("par", c["t"]), str(tmp_path / "out"))
+    assert r.returncode == 0, r.stdout
+    helpers.assert_same_tables(ex, inx, want, name)
+
+
 def test_executable_is_a_drop_in(tmp_path):
     name = "syn_k47_d2_L"
     c, want = helpers.golden_case(name)
