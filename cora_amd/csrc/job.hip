@@ -362,6 +362,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
             b_chain = job->pool.arena_bytes >= (size_t)dp.G * 70 ? 5 : job->pool.arena_bytes >= (size_t)dp.G * 56 ? 3 : 1;
             if (b_chain_env >= 1 && b_chain_env <= 5) b_chain = b_chain_env;
         }
+        const bool lds = seed_lds_finish(NR);
         auto make = [&](int q) -> int {
             RCQ(codes[q].alloc(NR)); RCQ(hists[q].alloc(tiles * 256));
             cp[q] = codes[q].p; hp[q] = hists[q].p;
@@ -376,14 +377,14 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         };
         if (!per_seed) {
             for (int q = 0; q < dp.nseeds; q++) RCQ(make(q));
-            launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, -1, seed_first_digit_shift());
+            launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, -1, seed_first_digit_shift(lds));
         }
         for (int seed = 1; seed <= dp.nseeds && NR; seed++) {
             if (per_seed) {
                 RCQ(make(seed - 1));
-                launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, seed - 1, seed_first_digit_shift());
+                launch_seed_codes_all(s, dp, job->pk.p, reps.p, NR, cp, hp, sk, tile_recs, seed - 1, seed_first_digit_shift(lds));
             }
-            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, sk.b[seed - 1], sk.c[seed - 1], nullptr, b_chain));
+            RCQ(st_seed_verify(job, codes[seed - 1], NR, seed, ps, hists[seed - 1].p, sk.b[seed - 1], sk.c[seed - 1], nullptr, b_chain, lds));
             codes[seed - 1].release(); hists[seed - 1].release(); skb[seed - 1].release(); skc[seed - 1].release();
             cp[seed - 1] = nullptr; hp[seed - 1] = nullptr; sk.b[seed - 1] = nullptr; sk.c[seed - 1] = nullptr;
         }

@@ -322,19 +322,32 @@ int st_pack(cora_hip_job *job);
 int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out);
 int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from = nullptr);
 inline int exact_sort_bits(const cora_hip_job *job) { return job->hash_bits ? job->hash_bits : 40; }     // the exact sort runs on the top bits of the hash
-// The seed sorts leave the last code byte to the candidate kernels, which order every bucket of equal top 24 bits in LDS
-// (kernels.hip, "the last sort digit in LDS"): three global passes instead of four.  CORA_SEED_LDS=0: four passes, as before round 3.
-inline bool seed_lds_finish() { static const bool on = !(getenv("CORA_SEED_LDS") && atoi(getenv("CORA_SEED_LDS")) == 0); return on; }
+// A seed sort of many records leaves the last code byte to the candidate kernels, which order every bucket of equal top 24 bits in
+// LDS (kernels.hip, "the last sort digit in LDS"): three global passes instead of four.  That pays when a bucket holds some tens of
+// records (2^24 buckets; a 64 Mbp reference, 4 records per bucket, spent twice the time in its seeds stage that way).  Measured on
+// the bench generator (profiles/seed_lds_threshold_ab.sh; seeds stage, four passes against three + LDS): 4.9e8 records 72.5 / 78.6 ms,
+// 9.5e8 141.3 / 138.5, 1.45e9 203.0 / 192.0, 2.9e9 413 / 377: from SEED_LDS_MIN_RECORDS on.  CORA_SEED_LDS=0: never (the four
+// passes of before round 3), 2: always (tests), a larger value: from that many records on.
+constexpr u64 SEED_LDS_MIN_RECORDS = 900000000ull;
+inline bool seed_lds_finish(u64 n_records)
+{
+    const char *e = getenv("CORA_SEED_LDS");
+    const long long v = e ? atoll(e) : 1;
+    if (v == 0) return false;
+    if (v == 2) return true;
+    return n_records >= (v > 2 ? (u64)v : SEED_LDS_MIN_RECORDS);
+}
 inline int seed_code_lo(bool with_sketch) { return with_sketch ? 96 : 32; }                             // a seed record's code: 32 bits from here
-inline int seed_sort_lo(bool with_sketch) { return seed_code_lo(with_sketch) + (seed_lds_finish() ? 8 : 0); }   // the bits its sort runs on start here
+inline int seed_sort_lo(bool with_sketch, bool lds) { return seed_code_lo(with_sketch) + (lds ? 8 : 0); }   // the bits its sort runs on start here
 inline int seed_sort_hi(bool with_sketch) { return seed_code_lo(with_sketch) + 32; }
-inline int seed_first_digit_shift() { return seed_lds_finish() ? 8 : 0; }                               // ... as a shift of the code (k_seed_codes_all's histograms)
+inline int seed_first_digit_shift(bool lds) { return lds ? 8 : 0; }                                     // ... as a shift of the code (k_seed_codes_all's histograms)
 int st_exact_parts(cora_hip_job *job, ExactLocal &x, ExactParts &p);
 int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &host_ms);
 int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBuf<u32> &reps, u64 &n_out);
 int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist = nullptr,
                    u64 *sk_b = nullptr, u32 *sk_c = nullptr /* [n] per-record sketches for the candidate kernels' pre-filter; sorted along */,
-                   const SortSource *from = nullptr, int b_chain_n = 1 /* sk_b is the first of that many arrays of n words (radix_sort's chain) */);
+                   const SortSource *from = nullptr, int b_chain_n = 1 /* sk_b is the first of that many arrays of n words (radix_sort's chain) */,
+                   bool lds = false /* seed_lds_finish: the sort stops above the last code byte (first_hist / from were made for that range) */);
 int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, FinishStats &fst, double &host_ms);
 void shard_state_free(cora_hip_job *job);
 // a second context on the job's device for work that runs beside the job's own stream (shard.hip: the exact table's finish):

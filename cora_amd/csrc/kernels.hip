@@ -1105,6 +1105,31 @@ __global__ __launch_bounds__(256) void k_seed_codes_all(DevParams p, const u64 *
     for (int s = 0; s < NS; s++) if ((only < 0 || s == only) && hists[s]) hists[s][(size_t)blockIdx.x * 256 + tid] = h[s][tid];
 }
 
+// The candidate kernels' test of a pair of records with one canonical, non-palindromic code on their sketches (k_seed_codes_all):
+// false = no slot.  More than d differing bases cannot be reported (HTS:2138-2265 aborts at > d); a pair that agrees on an
+// earlier seed's whole code has been reported by that seed (HTS:2222-2232; k_judge would dismiss it): DevParams::sk_early.
+struct EarlyWords {
+    u32 nh, nl, nc;                                       // 0 where the word holds an earlier seed's code, else 1
+    __device__ __forceinline__ explicit EarlyWords(u32 early) : nh((early & 1u) ? 0u : 1u), nl((early & 2u) ? 0u : 1u), nc((early & 4u) ? 0u : 1u) {}
+};
+template <bool SKB, bool SKC>
+__device__ __forceinline__ bool sketch_pass(u64 bi, u64 bj, u32 ci, u32 cj, int d, const EarlyWords &e)
+{
+    int mm = 0;
+    bool seen = false;
+    if (SKB) {
+        const u64 x = bi ^ bj;
+        mm += __popcll((x | (x >> 1)) & M55);
+        seen = (((u32)(x >> 32) | e.nh) == 0u) | (((u32)x | e.nl) == 0u);
+    }
+    if (SKC) {
+        const u32 y = ci ^ cj;
+        mm += __popc((y | (y >> 1)) & 0x55555555u);
+        seen = seen | ((y | e.nc) == 0u);
+    }
+    return mm <= d && !seen;
+}
+
 struct Mism { u64 hi, lo; };
 __device__ __forceinline__ Mism mism_of(u64 ah, u64 al, u64 bh, u64 bl)
 {
@@ -1231,6 +1256,7 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
     }
     __syncthreads();
     const bool have_sk = SKB || SKC;
+    const EarlyWords early(p.sk_early);
     u32 nslot = 0;
     u64 ncand = 0;
 #pragma unroll 1
@@ -1261,12 +1287,7 @@ __global__ __launch_bounds__(256) void k_candidates(DevParams p, const u64 *__re
                 return;
             }
             nc++;                                               // whatever the sketches say
-            if (filter) {
-                int mm = 0;
-                if (SKB) { const u64 x = bi ^ bj; mm += __popcll((x | (x >> 1)) & M55); }
-                if (SKC) { const u32 y = qi ^ qj; mm += __popc((y | (y >> 1)) & 0x55555555u); }
-                if (mm > p.d) return;
-            }
+            if (filter && !sketch_pass<SKB, SKC>(bi, bj, qi, qj, p.d, early)) return;
             if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = SLOT_PLAIN; at++; }
             else {
                 const u32 e = (lj >= 0 && nslot < 256u) ? atomicAdd(&s_n, 1u) : (u32)VT_QUOTA;
@@ -1466,6 +1487,7 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
     u32 wslots = 0, carry_o = 0, carry_P = 0;
     bool spill = false;
     u32 *mk = s_mk[wv];
+    const EarlyWords early(p.sk_early);
     for (u32 c0 = 0; c0 < W; c0 += VP_STRIP) {
 #pragma unroll
         for (int x = 0; x < VP_STRIP / 64; x++) mk[x * 64 + lane] = 0;
@@ -1485,10 +1507,7 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
             if (q < W) {
                 li = seg0 + (int)o_rec;
                 lj = li - (int)(q - o_P + 1u);
-                int mm = 0;
-                if (SKB) { const u64 x = s_b[li] ^ s_b[lj]; mm += __popcll((x | (x >> 1)) & M55); }
-                if (SKC) { const u32 y = s_c[li] ^ s_c[lj]; mm += __popc((y | (y >> 1)) & 0x55555555u); }
-                pass = mm <= p.d;
+                pass = sketch_pass<SKB, SKC>(SKB ? s_b[li] : 0ull, SKB ? s_b[lj] : 0ull, SKC ? s_c[li] : 0u, SKC ? s_c[lj] : 0u, p.d, early);
             }
             const u64 bal = __ballot(pass);
             if (pass) {
@@ -1802,6 +1821,7 @@ __global__ __launch_bounds__(256) void k_candidates_pairs_ps(DevParams p, const 
     u32 wslots = 0, carry_o = 0, carry_P = 0;
     bool spill = false;
     u32 *mk = s_mk[wv];
+    const EarlyWords early(p.sk_early);
     for (u32 c0 = 0; c0 < W; c0 += VP_STRIP) {
 #pragma unroll
         for (int x = 0; x < VP_STRIP / 64; x++) mk[x * 64 + lane] = 0;
@@ -1821,10 +1841,7 @@ __global__ __launch_bounds__(256) void k_candidates_pairs_ps(DevParams p, const 
             if (q < W) {
                 li = seg0 + (int)o_rec;
                 lj = li - (int)(q - o_P + 1u);
-                int mm = 0;
-                if (SKB) { const u64 x = s_b[li] ^ s_b[lj]; mm += __popcll((x | (x >> 1)) & M55); }
-                if (SKC) { const u32 y = s_c[li] ^ s_c[lj]; mm += __popc((y | (y >> 1)) & 0x55555555u); }
-                pass = mm <= p.d;
+                pass = sketch_pass<SKB, SKC>(SKB ? s_b[li] : 0ull, SKB ? s_b[lj] : 0ull, SKC ? s_c[li] : 0u, SKC ? s_c[lj] : 0u, p.d, early);
             }
             const u64 bal = __ballot(pass);
             if (pass) {
@@ -1938,6 +1955,7 @@ __global__ __launch_bounds__(256) void k_candidates_ps(DevParams p, const u64 *_
     bool cut_mid;
     ps_cuts<PS_WHALO>(s_heads, base, n, f, e, cut_mid);
     const bool have_sk = SKB || SKC;
+    const EarlyWords early(p.sk_early);
     u32 nslot = 0;
     u64 ncand = 0;
 #pragma unroll 1
@@ -1965,12 +1983,7 @@ __global__ __launch_bounds__(256) void k_candidates_ps(DevParams p, const u64 *_
                 return;
             }
             nc++;
-            if (filter) {
-                int mm = 0;
-                if (SKB) { const u64 x = bi ^ bj; mm += __popcll((x | (x >> 1)) & M55); }
-                if (SKC) { const u32 y = qi ^ qj; mm += __popc((y | (y >> 1)) & 0x55555555u); }
-                if (mm > p.d) return;
-            }
+            if (filter && !sketch_pass<SKB, SKC>(bi, bj, qi, qj, p.d, early)) return;
             if (WRITE) { slots[at].p1 = gi; slots[at].p2 = gj; slots[at].meta = SLOT_PLAIN; at++; }
             else {
                 const u32 en = (lj >= 0 && nslot < 256u) ? atomicAdd(&s_n, 1u) : (u32)VT_QUOTA;

@@ -24,12 +24,27 @@ struct DevParams {
     u64 seedmask_hi[4], seedmask_lo[4];   // one bit per base (bit 62-2i of word i/32) for seed s = index+1
     u64 pos_base;             // first position of the block range a window kernel works on (0 = whole genome)
     u32 any_windowed;         // d == 3 and some contig is compacted in 50 Mbp windows (HTS:2852-2856)
+    u32 sk_early;             // candidate kernels: sketch_early_words() of the seed at hand (set per launch; 0: no word is looked at)
     u8 sig2[16];              // physical group of (first,last) base pair
     const u64 *ctg_gstart;    // [n_contigs+1] start of each contig in the global coordinate (last = G)
     const u32 *ctg_len;       // [n_contigs]
     const u64 *ctg_off;       // [n_contigs] file offset of the first base
     const u32 *ctg_window;    // [n_contigs] 0 or the window length
 };
+
+// Which words of a seed record's sketch hold the code of an EARLIER seed.  The sketch of seed s (0-based) holds the codes of seeds
+// (s + 1) % NS, (s + 2) % NS, ... in this order: NS = 2: one word, c; NS = 3: the high and the low word of b; NS = 4: those and c
+// (k_seed_codes_all).  Bit 0: the high word of b, bit 1: its low word, bit 2: c.  A pair that agrees on an earlier seed is reported
+// by that seed and by no later one (HTS:2222-2232): the candidate kernels give it no slot.
+inline u32 sketch_early_words(int s, int ns)
+{
+    if (ns == 2) return s == 1 ? 4u : 0u;
+    u32 m = 0;
+    if ((s + 1) % ns < s) m |= 1u;
+    if ((s + 2) % ns < s) m |= 2u;
+    if (ns == 4 && (s + 3) % ns < s) m |= 4u;
+    return m;
+}
 
 // pair record meta / item meta bit layout
 //   bit 0      dir

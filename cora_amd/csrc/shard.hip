@@ -312,7 +312,9 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
         if (sh.filter) {
             const SortSource from = source_of(sh, 2, sh.seed_sketch, false);
             u64 kept = 0;
-            if (radix_sort_count_kept(s, from, seed_sort_lo(sh.seed_sketch), seed_sort_hi(sh.seed_sketch), job->sort_scratch, &kept)) return fail(100, "radix sort failed");
+            // (the bit range must be fixed before the kept records have been counted: a rank keeps about its share of them)
+            const bool lds = seed_lds_finish(sh.n_send / (u64)sh.world);
+            if (radix_sort_count_kept(s, from, seed_sort_lo(sh.seed_sketch, lds), seed_sort_hi(sh.seed_sketch), job->sort_scratch, &kept)) return fail(100, "radix sort failed");
             if (kept) {
                 RCQ(sh.recv_a.alloc(kept));
                 // the sketches' second word climbs through a chain of arrays when the arena has the room (job.hip: why)
@@ -322,7 +324,7 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
                     if (chain > 1 && sh.recv_b.alloc(kept * (u64)chain)) { chain = 1; (void)hipGetLastError(); }
                     if (chain == 1) RCQ(sh.recv_b.alloc(kept));
                 }
-                RCQ(st_seed_verify(job, sh.recv_a, kept, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, &from, chain));
+                RCQ(st_seed_verify(job, sh.recv_a, kept, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, &from, chain, lds));
             }
             sh.recv_a.release(); sh.send_a.release(); sh.recv_b.release(); sh.send_b.release();
             sh.n_send = sh.n_recv = 0;
@@ -330,7 +332,8 @@ extern "C" int cora_hip_shard_stage(cora_hip_job *job, int stage, int arg, uint6
             return 0;
         }
         if (sh.seed_sketch && sh.n_recv && !sh.recv_b.p) return fail(19, "the seed records' sketches have not been delivered");
-        if (sh.n_recv) RCQ(st_seed_verify(job, sh.recv_a, sh.n_recv, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, nullptr, sh.seed_sketch ? sh.b_chain : 1));
+        if (sh.n_recv) RCQ(st_seed_verify(job, sh.recv_a, sh.n_recv, arg, sh.ps, nullptr, sh.seed_sketch ? sh.recv_b.p : nullptr, nullptr, nullptr, sh.seed_sketch ? sh.b_chain : 1,
+                                              seed_lds_finish(sh.n_recv)));
         sh.recv_a.release(); sh.send_a.release(); sh.recv_b.release(); sh.send_b.release();
         job->stats.hom_pairs = sh.ps.n;
         return 0;

@@ -241,9 +241,11 @@ int st_reps(cora_hip_job *job, const u32 *repmask, u64 word_lo, u64 word_hi, DBu
 // sk_b / sk_c: the records' sketches (k_seed_codes_all), sorted along with them; either or both may be null.
 // from: as in st_exact_classes (the bit range is seed_sort_lo / _hi); codes / sk_b are then only sized for the n kept records.
 int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairStore &ps, u32 *first_hist, u64 *sk_b, u32 *sk_c, const SortSource *from,
-                   int b_chain_n)
+                   int b_chain_n, bool lds)
 {
-    const DevParams &dp = job->dp;
+    DevParams dp = job->dp;
+    // (the candidate kernels' copy: which sketch words hold an earlier seed's code; CORA_SK_EARLY=0: none is looked at, the A/B switch)
+    dp.sk_early = (getenv("CORA_SK_EARLY") && atoi(getenv("CORA_SK_EARLY")) == 0) ? 0u : sketch_early_words(seed - 1, dp.nseeds);
     hipStream_t s = job->stream;
     if (!n) return 0;
     DBuf<u64> codes_tmp, tots;
@@ -256,9 +258,9 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     else if (sk_b) { RCQ(skb_tmp.alloc(n)); ck.b = sk_b; ct.b = skb_tmp.p; }               // the sketches travel with their records
     if (sk_c) { RCQ(skc_tmp.alloc(n)); ck.c = sk_c; ct.c = skc_tmp.p; }
     // the records are a (code << 32 | position); with a b array the sort's logical key is a:b, i.e. a's bits sit 64 higher
-    const int key_lo = seed_sort_lo(sk_b != nullptr), key_hi = seed_sort_hi(sk_b != nullptr);
+    const int key_lo = seed_sort_lo(sk_b != nullptr, lds), key_hi = seed_sort_hi(sk_b != nullptr);
     if (radix_sort(s, ck, ct, n, key_lo, key_hi, job->sort_scratch, &job->sort_timing, first_hist, from)) return fail(100, "radix sort failed");
-    const bool lds = seed_lds_finish();                           // the records are sorted on the top 24 code bits; the candidate kernels order the rest in LDS
+    // lds: the records are now sorted on the top 24 code bits; the candidate kernels order the rest in LDS
     const u64 ab = lds ? verify_blocks_ps(n) : verify_blocks(n);  // workgroups (tiles) of the candidate kernels
     const u64 vt = lds ? 2 * ab : ab;                             // per-tile entries (PS: the balanced kernel's, then the walk's)
     u64 totals[2] = {0, 0};                                      // slots, comparisons

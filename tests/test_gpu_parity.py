@@ -11,6 +11,8 @@ import pytest
 import helpers
 from cora_amd import hip, synth
 
+from conftest import BOTH_SEED_SORTS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -178,8 +180,9 @@ def test_pack_and_kmers_match_numpy(tmp_path):
 
 
 # ------------------------------------------------------------------ whole tables vs the real reference
+@BOTH_SEED_SORTS
 @pytest.mark.parametrize("name", sorted(n for n, c in helpers.MANIFEST["cases"].items() if not c.get("hash_only")))
-def test_tables_match_reference_golden(name):
+def test_tables_match_reference_golden(name, seed_sort):
     c, want = helpers.golden_case(name)
     e, en, i, inn, st = hip.build_tables(helpers.input_path(c["input"]), c["K"], c["d"],
                                          helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
@@ -188,14 +191,13 @@ def test_tables_match_reference_golden(name):
     assert i == helpers.read(os.path.join(want, "Inexact")), "%s: Inexact differs" % name
 
 
+@BOTH_SEED_SORTS
 @pytest.mark.parametrize("name", ["syn_k50_d2_p10t8", "pal_k50_d2", "lowcx_k64_d3", "fam_k48_d3", "ecoli_like_k50_d2"])
-def test_four_pass_seed_sort_is_still_there(name, tmp_path, monkeypatch):
-    """Round 3 moved the last byte of the seed sort into the candidate kernels (three global passes; kernels.hip, "the last sort digit
-    in LDS"), which every other test now runs.  CORA_SEED_LDS=0 keeps the four-pass sort with the round-2 candidate kernels (the A/B
-    switch of DESIGN.md section 4): same tables.  The switch is read once per process, hence the executable."""
+def test_executable_with_either_seed_sort(name, seed_sort, tmp_path):
+    """The seed sorts run four global passes, or three with the last code byte ordered in LDS by the candidate kernels (from 2**30
+    records on; kernels.hip, "the last sort digit in LDS").  CORA_SEED_LDS = 0 / 2 forces either (tests/conftest.py): same tables."""
     c, want = helpers.golden_case(name)
     exe = os.path.join(hip.BIN_DIR, "homTable_setup_L" if c["L"] else "homTable_setup")
-    monkeypatch.setenv("CORA_SEED_LDS", "0")
     ex, inx, r = helpers.run_tool(exe, helpers.input_path(c["input"]), c["K"], c["d"], helpers.split_path("phys", c["p"]),
                                   helpers.split_path("par", c["t"]), str(tmp_path / "out"))
     assert r.returncode == 0, r.stdout
@@ -218,8 +220,9 @@ def test_executable_is_a_drop_in(tmp_path):
 
 
 # ------------------------------------------------------------------ seeded inputs vs the oracle
+@BOTH_SEED_SORTS
 @pytest.mark.parametrize("seed,K,d,p,t", [(1, 50, 2, 1, 1), (2, 33, 1, 3, 2), (3, 64, 3, 2, 4), (4, 41, 3, 1, 8), (5, 58, 2, 10, 8)])
-def test_seeded_genomes_match_oracle(seed, K, d, p, t, tmp_path):
+def test_seeded_genomes_match_oracle(seed, K, d, p, t, seed_sort, tmp_path):
     fams = [(400, 9, 0.02, 3), (150, 30, 0.01, 2), (90, 5, 0.0, 0)]
     contigs = synth.genome_with_families(100 + seed, 150_000, fams, n_runs=[(5000, 70), (149_000, 3)], lower=[(8000, 500)], name="s%d" % seed)
     contigs.append(("tail", synth.mutate(np.random.RandomState(seed), contigs[0][1][20_000:26_000], 0.01)))
@@ -254,10 +257,12 @@ def test_hash_collisions_are_repaired(name, bits, expect, monkeypatch):
 # ------------------------------------------------------------------ sketch pre-filter of the verification (large references)
 @pytest.mark.parametrize("name", ["syn_k50_d2", "syn_k50_d1", "syn_k64_d3", "syn_k33_d2", "lowcx_k36_d1", "lowcx_k64_d3", "pal_k50_d2_p4t5",
                                   "q_k50_d2_p10", "fam_k48_d3", "multi_k50_d2_L", "ecoli_like_k50_d2"])
-def test_sketch_prefilter_changes_nothing(name, monkeypatch):
-    """Above 2**30 representatives every seed record carries a 4-byte sketch through its sort and k_verify dismisses
-    partners whose sketches differ in more than d bases.  CORA_SKETCH=1 forces that path on the small fixtures: same
-    bytes, same number of comparisons counted."""
+@BOTH_SEED_SORTS
+def test_sketch_prefilter_changes_nothing(name, seed_sort, monkeypatch):
+    """Above 2**28 representatives every seed record carries the other seeds' codes through its sort as a sketch, and the candidate
+    kernels dismiss partners whose sketches differ in more than d bases or agree on an earlier seed's code (reported by that seed,
+    HTS:2222-2232).  CORA_SKETCH=1 forces that path on the small fixtures: same bytes, same number of comparisons counted, and no
+    more slots than without."""
     c, want = helpers.golden_case(name)
     args = (helpers.input_path(c["input"]), c["K"], c["d"], helpers.split_path("phys", c["p"]), helpers.split_path("par", c["t"]), bool(c["L"]))
     monkeypatch.setenv("CORA_SKETCH", "0")
@@ -267,6 +272,7 @@ def test_sketch_prefilter_changes_nothing(name, monkeypatch):
     assert e == helpers.read(os.path.join(want, "Exact")) and i == helpers.read(os.path.join(want, "Inexact"))
     assert (e0, i0) == (e, i)
     assert st["candidate_pairs"] == st0["candidate_pairs"] and st["hom_pairs"] == st0["hom_pairs"]
+    assert st["hom_pairs"] <= st["verify_slots"] <= st0["verify_slots"]
 
 
 # ------------------------------------------------------------------ the benchmark workload at full size
