@@ -366,10 +366,21 @@ bool serialize_inexact(const HostGenome &g, const InexactDeviceResult &r, View<u
     std::vector<FinishStats> sts(parts);
     std::vector<std::thread> th;
     std::vector<char> ok(parts, 1);
-    for (size_t k = 1; k < parts; k++)
-        th.emplace_back([&, k]() { ok[k] = serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k], marks ? marks->data() + cut[k] : nullptr); });
-    ok[0] = serialize_inexact_range(g, r, packed, cut[0], cut[1], bufs[0], sts[0], marks ? marks->data() + cut[0] : nullptr);
+    std::vector<double> part_ms(parts, 0.0);
+    auto one = [&](size_t k) {
+        const auto t0 = std::chrono::steady_clock::now();
+        ok[k] = serialize_inexact_range(g, r, packed, cut[k], cut[k + 1], bufs[k], sts[k], marks ? marks->data() + cut[k] : nullptr);
+        part_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    for (size_t k = 1; k < parts; k++) th.emplace_back(one, k);
+    one(0);
     for (auto &x : th) x.join();
+    if (getenv("CORA_TRACE")) {
+        fprintf(stderr, "[cora]   host lists, per thread (ms / items / lists finished in the reference's order):");
+        for (size_t k = 0; k < parts; k++)
+            fprintf(stderr, " %.2f/%u/%llu", part_ms[k], (unsigned)(r.node_start[cut[k + 1]] - r.node_start[cut[k]]), (unsigned long long)sts[k].dirty_nodes);
+        fprintf(stderr, "\n");
+    }
     for (size_t k = 0; k < parts; k++) if (!ok[k]) return false;
     std::vector<size_t> off(parts + 1, 0);
     for (size_t k = 0; k < parts; k++) {

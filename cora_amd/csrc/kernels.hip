@@ -2465,9 +2465,27 @@ __global__ __launch_bounds__(256) void k_node_size(DevParams p, int cw, const u3
     if ((threadIdx.x & 63) == 0) { s_emit[threadIdx.x >> 6] = (u32)__popcll(bal); s_big[threadIdx.x >> 6] = (u32)__popcll(bbig); }
     __syncthreads();
     if (threadIdx.x == 0) {                                    // per-block partials: two same-address atomics per block were half of this kernel's 7.2 ms
-        blk_counts[2 * blockIdx.x] = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3];
-        blk_counts[2 * blockIdx.x + 1] = s_big[0] + s_big[1] + s_big[2] + s_big[3];
+        blk_counts[blockIdx.x] = s_emit[0] + s_emit[1] + s_emit[2] + s_emit[3];       // (also what k_node_emit_list's offsets are scanned from)
+        blk_counts[gridDim.x + blockIdx.x] = s_big[0] + s_big[1] + s_big[2] + s_big[3];
     }
+}
+
+// The lists the device writes (size != 0), listed in list order: block b's go to list[blk_off[b] ..] (blk_off = the scanned per-block
+// counts of k_node_size).  Three lists in four have had all their items absorbed by the block merge and are not written: k_node_write
+// over ALL lists ran with a quarter of its lanes busy, and its time is latency (contig searches, byte stores), i.e. per wave.
+__global__ __launch_bounds__(256) void k_node_emit_list(const u32 *__restrict__ size, u32 n_nodes, const u64 *__restrict__ blk_off, u32 *__restrict__ list)
+{
+    __shared__ u32 s_w[4];
+    const u32 nd = blockIdx.x * 256 + threadIdx.x;
+    const bool e = nd < n_nodes && size[nd] != 0;
+    const u64 bal = __ballot(e);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_w[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    if (!e) return;
+    u32 pre = 0;
+    for (int w = 0; w < wv; w++) pre += s_w[w];
+    list[blk_off[blockIdx.x] + pre + (u32)__popcll(bal & ((1ull << lane) - 1ull))] = nd;
 }
 
 // emitted_nodes / big_nodes += the per-block pairs of k_node_size (one atomic per field and workgroup of a 64-workgroup grid)
@@ -2475,7 +2493,7 @@ __global__ __launch_bounds__(256) void k_node_counts(const u32 *__restrict__ blk
 {
     __shared__ unsigned long long s_e[4], s_b[4];
     unsigned long long e = 0, b = 0;
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n_blocks; i += gridDim.x * 256) { e += blk_counts[2 * i]; b += blk_counts[2 * i + 1]; }
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n_blocks; i += gridDim.x * 256) { e += blk_counts[i]; b += blk_counts[n_blocks + i]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); b += __shfl_xor(b, o, 64); }
     if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = e; s_b[threadIdx.x >> 6] = b; }
@@ -2497,10 +2515,12 @@ __global__ __launch_bounds__(256) void k_node_write(DevParams p, int cw, const u
                                                     const u64 *__restrict__ hidx, const u64 *__restrict__ hoff, const u32 *__restrict__ node_tie,
                                                     u8 *__restrict__ stream, HostNode *__restrict__ hnodes, u64 *__restrict__ h_key,
                                                     u32 *__restrict__ h_meta, int16_t *__restrict__ h_blen, u32 *__restrict__ ord, u32 node_lo,
-                                                    int which /* 1: the lists the host finishes, 2: the others, 3: all */)
+                                                    int which /* 1: the lists the host finishes, 2: the others, 3: all */,
+                                                    const u32 *__restrict__ elist /* null, or k_node_emit_list's: node_lo / n_nodes are then places in it */)
 {
-    const u32 nd = node_lo + blockIdx.x * 256 + threadIdx.x;           // lists node_lo .. n_nodes-1
+    u32 nd = node_lo + blockIdx.x * 256 + threadIdx.x;                 // lists node_lo .. n_nodes-1
     if (nd >= n_nodes) return;
+    if (elist) nd = elist[nd];
     const bool for_host = hflag[nd] != 0;
     if (!(which & (for_host ? 1 : 2))) return;
     const u32 a = node_start[nd], b = node_start[nd + 1];
@@ -2724,10 +2744,14 @@ void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 node_lo, u32 node_hi, const u32 *size, const u64 *off, const u32 *hflag, const u64 *hidx,
                        const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen, u32 *ord,
-                       int which)
+                       int which, const u32 *elist)
 {
     if (node_hi > node_lo) hipLaunchKernelGGL(k_node_write, grid_for(node_hi - node_lo), dim3(256), 0, s, p, cw, item_key, item_meta, blen, node_start,
-                                              node_hi, size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen, ord, node_lo, which);
+                                              node_hi, size, off, hflag, hidx, hoff, node_tie, stream, hnodes, h_key, h_meta, h_blen, ord, node_lo, which, elist);
+}
+void launch_node_emit_list(hipStream_t s, const u32 *size, u32 n_nodes, const u64 *blk_off, u32 *list)
+{
+    if (n_nodes) hipLaunchKernelGGL(k_node_emit_list, grid_for(n_nodes), dim3(256), 0, s, size, n_nodes, blk_off, list);
 }
 
 void launch_pack(hipStream_t s, const DevParams &p, const u8 *raw, u64 *pk, u32 *bad, DevCounters *ctr)

@@ -170,12 +170,15 @@ void launch_exact_write(hipStream_t s, const DevParams &p, int cw, const u32 *cl
 void launch_node_class(hipStream_t s, const DevParams &p, const u64 *item_key, const u32 *node_start, u32 n_nodes, u32 *run_head, u32 *node_tie);
 void launch_run_dirty(hipStream_t s, const u32 *node_tie, const u64 *run_excl, const u32 *run_head, u32 n_nodes, u32 *run_dirty);
 void launch_node_size(hipStream_t s, const DevParams &p, int cw, const u32 *node_start, const int16_t *blen, const u64 *run_excl,
-                      const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, u32 *blk_counts /* [2 * ceil(n_nodes / 256)] scratch */, DevCounters *ctr);
+                      const u32 *run_head, const u32 *run_dirty, u32 n_nodes, u32 *size, u32 *hflag, u32 *hcnt, u32 *blk_counts /* [2 * ceil(n_nodes / 256)]: device-written lists per block of 256 lists, then the lists above 16 items */, DevCounters *ctr);
 void launch_node_write(hipStream_t s, const DevParams &p, int cw, const u64 *item_key, const u32 *item_meta, const int16_t *blen,
                        const u32 *node_start, u32 node_lo, u32 node_hi /* lists node_lo .. node_hi-1 */, const u32 *size, const u64 *off,
                        const u32 *hflag, const u64 *hidx, const u64 *hoff, const u32 *node_tie, u8 *stream, HostNode *hnodes, u64 *h_key, u32 *h_meta, int16_t *h_blen,
                        u32 *ord /* [items] scratch of the lists above 16 items */,
-                       int which /* 1: only the lists the host finishes (hflag), 2: only the others, 3: all */);
+                       int which /* 1: only the lists the host finishes (hflag), 2: only the others, 3: all */,
+                       const u32 *elist = nullptr /* launch_node_emit_list's list: node_lo / node_hi are then places in it */);
+// the lists with size != 0, in list order; blk_off: the exclusive scan of launch_node_size's first ceil(n_nodes / 256) block counts
+void launch_node_emit_list(hipStream_t s, const u32 *size, u32 n_nodes, const u64 *blk_off, u32 *list);
 void launch_test_list_sort(hipStream_t s, u32 *e, u64 n, long forced_depth);
 
 }  // namespace cora

@@ -443,19 +443,32 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         if (exclusive_scan_u32_to_u64(s, nsize.p, noff.p, nn, scr.p, tots.p)) return fail(100, "scan launch failed");
         if (exclusive_scan_u32_to_u64(s, hflag.p, hidx.p, nn, scr.p, tots.p + 1)) return fail(100, "scan launch failed");
         if (exclusive_scan_u32_to_u64(s, hcnt.p, hoff.p, nn, scr.p, tots.p + 2)) return fail(100, "scan launch failed");
-        u64 totals[3] = {0, 0, 0};                          // stream bytes, host lists, their items
+        // the lists the device writes, listed: most lists have lost all their items to the block merge (kernels.hip, k_node_emit_list)
+        const u64 size_blocks = ((u64)nn + 255) / 256;
+        DBuf<u64> eoff;
+        DBuf<u32> elist;
+        RCQ(eoff.alloc(size_blocks + 1));
+        if (exclusive_scan_u32_to_u64(s, size_counts.p, eoff.p, size_blocks, scr.p, tots.p + 3)) return fail(100, "scan launch failed");
+        HIPQ(hipMemcpyAsync(eoff.p + size_blocks, tots.p + 3, sizeof(u64), hipMemcpyDeviceToDevice, s));
+        u64 totals[4] = {0, 0, 0, 0};                       // stream bytes, host lists, their items, device-written lists
         HIPQ(hipMemcpyAsync(totals, tots.p, sizeof totals, hipMemcpyDeviceToHost, s));
         // the byte stream is written and sent in up to STREAM_PIECES pieces of consecutive lists: where each piece starts.  (What the
         // host still has to do when the device is done is the last piece's copy and its move into place: 7 ms with four pieces.)
         constexpr int PIECES = STREAM_PIECES;
         const int pieces = nn >= (1u << 20) ? PIECES : 1;
         u32 piece_node[PIECES + 1];
-        u64 piece_off[PIECES + 1];
+        u64 piece_off[PIECES + 1], piece_list[PIECES + 1];      // ... in the byte stream, in the list of device-written lists
         for (int c = 0; c <= pieces; c++) piece_node[c] = (u32)((u64)nn * c / pieces) & ~255u;
         piece_node[pieces] = nn;
-        for (int c = 1; c < pieces; c++) HIPQ(hipMemcpyAsync(&piece_off[c], noff.p + piece_node[c], sizeof(u64), hipMemcpyDeviceToHost, s));
+        for (int c = 1; c < pieces; c++) {
+            HIPQ(hipMemcpyAsync(&piece_off[c], noff.p + piece_node[c], sizeof(u64), hipMemcpyDeviceToHost, s));
+            HIPQ(hipMemcpyAsync(&piece_list[c], eoff.p + piece_node[c] / 256, sizeof(u64), hipMemcpyDeviceToHost, s));
+        }
         HIPQ(hipStreamSynchronize(s));
         piece_off[0] = 0; piece_off[pieces] = totals[0];
+        piece_list[0] = 0; piece_list[pieces] = totals[3];
+        RCQ(elist.alloc(totals[3]));
+        launch_node_emit_list(s, nsize.p, nn, eoff.p, elist.p);
         trace_mark(job, "items: sizes + scans", 5);
         DBuf<u8> stream;
         DBuf<HostNode> hnodes;
@@ -491,8 +504,8 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         //    k_node_write does); the host moves each piece to its place when it has arrived (assemble_inexact below)
         arrival.upto.clear();
         for (int c = 0; c < pieces; c++) {
-            launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, piece_node[c], piece_node[c + 1], nsize.p, noff.p, hflag.p, hidx.p, hoff.p,
-                              node_tie.p, stream.p, hnodes.p, hk.p, hm.p, hbl.p, ord.p, 2);
+            launch_node_write(s, dp, cw, kk.a, kk.c, blen.p, nstart.p, (u32)piece_list[c], (u32)piece_list[c + 1], nsize.p, noff.p, hflag.p, hidx.p, hoff.p,
+                              node_tie.p, stream.p, hnodes.p, hk.p, hm.p, hbl.p, ord.p, 2, elist.p);
             HIPQ(hipEventRecord(job->ev_copy[EV_WRITTEN + c], s));
             HIPQ(hipStreamWaitEvent(job->copy_stream, job->ev_copy[EV_WRITTEN + c], 0));
             if (piece_off[c + 1] > piece_off[c])
