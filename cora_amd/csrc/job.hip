@@ -112,6 +112,7 @@ int set_reference_impl(cora_hip_job *job, const cora_hip_contig *contigs, int32_
     if (!job->prm.chr_short && n_contigs > 127)
         return fail(19, "%d contigs need the 2-byte layout (homTable_setup_L; cora.cpp:25,488-493)", n_contigs);
     if (n_contigs > 65530) return fail(19, "too many contigs (%d)", n_contigs);                                            // HTS:23-27
+    join_warm(job);
     if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }
     HostGenome &hg = job->hg;
     hg.gstart.assign(n_contigs + 1, 0);
@@ -241,9 +242,9 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     static const int arena_end = getenv("CORA_ARENA_HIGH") ? atoi(getenv("CORA_ARENA_HIGH")) : -1;
     job->pool.ranges.big_from_high = arena_end != 0;
     // ---- stage 1: pack, hashed K-mer records (HTS:2499-2565) ----
-    if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }   // (a run that failed half-way)
+    join_warm(job);                                                                                                 // (a run that failed half-way)
+    if (job->packed_in_flight) { HIPQ(hipStreamSynchronize(job->copy_stream)); job->packed_in_flight = false; }
     RCQ(st_pack(job));
-    join_warm(job);
     const size_t packed_words = dp.n_words + 4;
     if (job->h_packed.cap < packed_words && !job->h_stream.cap && !job->inexact_bytes.p && job->genome_bases >= (256ull << 20)) {
         // The first build of a job on a large reference pays for its host buffers: pinning the landing areas of the packed
@@ -255,6 +256,18 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         // The packed reference then travels when st_items_finish asks for it (15 ms) instead of right now.
         const size_t est = (size_t)(job->genome_bases / 5 * 2);
         const int dev = job->device;
+        HIPQ(hipEventRecord(job->ev_copy[EV_PACKED_READY], s));          // (k_pack has been launched: the packed reference may leave behind it)
+        // the landing area and the host buffer of <Exact> in a thread of their own: the exact stage is through 0.15 s from now, and the
+        // device waited 31 ms for these two in a first build (0.02 B per base on the GRCh38-like workload; 1/32 is reserved)
+        job->warm_exact = std::thread([job, dev] {
+            if (hipSetDevice(dev) != hipSuccess) return;
+            const size_t est_exact = (size_t)(job->genome_bases / 32) + (1u << 20);
+            const auto w0 = std::chrono::steady_clock::now();
+            if (!job->h_exact.reserve(est_exact)) { uint8_t x = 0; for (size_t o = 0; o < est_exact; o += 4096) x ^= ((const volatile uint8_t *)job->h_exact.p)[o]; (void)x; }
+            if (job->exact_bytes.reserve_uninit(est_exact))
+                for (size_t o = 0; o < est_exact; o += 4096) job->exact_bytes.p[o] = 0;
+            if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] warm: <Exact> buffers ready after %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+        });
         job->warm = std::thread([job, est, dev, packed_words] {
             if (hipSetDevice(dev) != hipSuccess) return;
             auto touch = [](const volatile uint8_t *p, size_t n) { uint8_t x = 0; for (size_t o = 0; o < n; o += 4096) x ^= p[o]; return x; };
@@ -268,18 +281,32 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
                     for (size_t o = 0; o < est; o += 4096) job->inexact_bytes.p[o] = 0;
                 if (trace) fprintf(stderr, "[cora] warm: table pages touched after %.1f ms\n", since());
             });
-            if (!job->h_packed.reserve(packed_words)) (void)touch((const uint8_t *)job->h_packed.p, packed_words * sizeof(u64));
+            // (the byte stream's landing area, the largest, in a thread of its own)
+            std::thread stream_area([job, est, touch, since] {
+                if (!job->h_stream.reserve(est)) (void)touch(job->h_stream.p, est);
+                if (trace) fprintf(stderr, "[cora] warm: byte-stream landing area pinned after %.1f ms\n", since());
+            });
+            if (!job->h_packed.reserve(packed_words)) {
+                (void)touch((const uint8_t *)job->h_packed.p, packed_words * sizeof(u64));
+                // ... and the packed reference leaves for it at once, on the copy stream (nobody else uses that stream before
+                // st_items_finish has joined this thread): asked for by st_items_finish it took 15 ms of the items stage
+                if (hipStreamWaitEvent(job->copy_stream, job->ev_copy[EV_PACKED_READY], 0) == hipSuccess &&
+                    hipMemcpyAsync(job->h_packed.p, job->pk.p, packed_words * sizeof(u64), hipMemcpyDeviceToHost, job->copy_stream) == hipSuccess &&
+                    hipEventRecord(job->ev_copy[EV_PACKED_ARRIVED], job->copy_stream) == hipSuccess)
+                    job->packed_in_flight = true;          // (read after join_warm)
+                else (void)hipGetLastError();
+            }
             if (trace) fprintf(stderr, "[cora] warm: packed-reference landing area pinned after %.1f ms\n", since());
-            if (!job->h_stream.reserve(est)) (void)touch(job->h_stream.p, est);
-            if (trace) fprintf(stderr, "[cora] warm: byte-stream landing area pinned after %.1f ms\n", since());
             // the landing areas of the lists the host finishes (tied targets): one list per 2048 bases and one item per 512 are
             // four times what the GRCh38-like workload needs; pinned here, st_items_finish finds them ready (2-3 ms of hipHostMalloc each)
             const size_t lists = (size_t)(job->genome_bases / 2048) + 1024, items = (size_t)(job->genome_bases / 512) + 4096;
             (void)job->h_hnodes.reserve(lists); (void)job->h_node_start.reserve(lists + 1);
             (void)job->h_key.reserve(items); (void)job->h_meta.reserve(items); (void)job->h_blen.reserve(items);
             if (trace) fprintf(stderr, "[cora] warm: host-list landing areas pinned after %.1f ms\n", since());
+            stream_area.join();
             table.join();
         });
+        if (getenv("CORA_WARM_SYNC")) join_warm(job);          // (diagnostic: the buffers first, then the kernels)
     } else {
         // the packed reference starts its way to the host now (0.25 B per base over PCIe beside 0.8 s of kernels): lists
         // with tied targets are finished there and read their K-mers from it (st_items_finish)
@@ -419,6 +446,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
     st.n_sort_scatter = job->sort_timing.scatter_launches;
     st.sort_scatter_bytes = job->sort_timing.scatter_bytes;
     st.pool_peak_bytes = job->pool.peak_live;
+    if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] stages: pack+records %.3f exact %.3f seeds %.3f items %.3f ms (device), host %.3f ms\n", st.ms_pack, st.ms_exact, st.ms_seeds,
+                                      st.ms_items, st.ms_host_finish);
     if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] run %.3f ms; device pool: %zu blocks, %zu hipMalloc calls so far (%.1f MB), most in use at once %.1f MB\n",
                                       st.ms_total, job->pool.blocks.size(), job->pool.n_malloc, job->pool.malloc_bytes / 1e6, job->pool.peak_live / 1e6);
     return 0;

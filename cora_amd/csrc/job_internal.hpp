@@ -235,6 +235,7 @@ struct cora_hip_job {
     // First build of a job on a large reference: a helper thread pins h_stream and faults in the pages of inexact_bytes
     // beside the kernels (job.hip); whoever touches either buffer calls join_warm first.
     std::thread warm;
+    std::thread warm_exact;               // ... and <Exact>'s two buffers, wanted first (st_exact_finish joins this one only)
     // cora_hip_job_set_table_files: <Inexact> is assembled in a mapping of its file (inexact_bytes is then file-backed), <Exact> is
     // written by a helper thread as soon as it is finished, beside the inexact stages
     std::string exact_path;
@@ -243,7 +244,8 @@ struct cora_hip_job {
     cora_hip_stats stats;
 };
 
-inline void join_warm(cora_hip_job *job) { if (job->warm.joinable()) job->warm.join(); }
+inline void join_warm_exact(cora_hip_job *job) { if (job->warm_exact.joinable()) job->warm_exact.join(); }       // before exact_bytes / h_exact are touched
+inline void join_warm(cora_hip_job *job) { join_warm_exact(job); if (job->warm.joinable()) job->warm.join(); }
 inline void join_exact_writer(cora_hip_job *job) { if (job->exact_writer.joinable()) job->exact_writer.join(); }
 
 inline int read_counters(cora_hip_job *job, DevCounters &h)

@@ -199,6 +199,7 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
         RCQ(stream.alloc(total));
         launch_exact_write(s, dp, cw, ce_s.p, eoff_s.p, p.ent.p, p.edir.p, mp.p, (u32)n, csize.p, coff.p, stream.p, job->ctr.p);
         View<u8> bytes;
+        join_warm_exact(job);                                                  // (a first build prepares these buffers beside the kernels, job.hip)
         RCQ(d2h(job, job->h_exact, bytes, (const u8 *)stream.p, total));      // (its own landing area: h_stream may still be in preparation, job.hip)
         RCQ(read_counters(job, h));
         HIPQ(hipGetLastError());
@@ -209,6 +210,7 @@ int st_exact_finish(cora_hip_job *job, ExactParts &p, FinishStats &fst, double &
         fst.exact_nodes = h.emitted_exact;
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
     } else {
+        join_warm_exact(job);
         if (!job->exact_bytes.reserve_uninit(16)) return fail(101, "host allocation failed");
         job->exact_bytes.n = 0;
         fst.exact_nodes = 0;
