@@ -86,6 +86,34 @@ __global__ __launch_bounds__(THREADS) void rs_hist(const u64 *__restrict__ w, u6
     if (tid < 256) tile_hist[(size_t)blockIdx.x * 256 + tid] = h[tid];
 }
 
+// The same histogram from the digit bytes the previous pass's scatter left in output order (SortScratch::next_digit).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void rs_hist_bytes(const unsigned char *__restrict__ nd, u64 n, u32 *__restrict__ tile_hist)
+{
+    constexpr int RS_TILE = THREADS * RS_IPT;
+    static_assert(RS_IPT == 16, "one 16-byte load per thread");
+    __shared__ u32 h[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) h[tid] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+    if (base + RS_TILE <= n && ((size_t)nd & 15) == 0) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(nd + base) + tid;
+        u32 w[4];
+        w[0] = __builtin_nontemporal_load(&p->x); w[1] = __builtin_nontemporal_load(&p->y);
+        w[2] = __builtin_nontemporal_load(&p->z); w[3] = __builtin_nontemporal_load(&p->w);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&h[w[k] & 255u], 1u); atomicAdd(&h[(w[k] >> 8) & 255u], 1u);
+            atomicAdd(&h[(w[k] >> 16) & 255u], 1u); atomicAdd(&h[w[k] >> 24], 1u);
+        }
+    } else {
+        for (u64 i = base + tid; i < n && i < base + RS_TILE; i += THREADS) atomicAdd(&h[nd[i]], 1u);
+    }
+    __syncthreads();
+    if (tid < 256) tile_hist[(size_t)blockIdx.x * 256 + tid] = h[tid];
+}
+
 // Offsets: the run of digit d of tile t starts at  sum of all counts of digits < d  +  counts of d in tiles < t.
 //   rs_colsum    per chunk of RS_CHUNK_TILES tiles: count of every digit               [chunks][256]
 //   rs_chunkscan one workgroup: per digit, exclusive scan over the chunks + the digit's base
@@ -194,7 +222,8 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
                                                           const u32 *__restrict__ c_in, u64 *__restrict__ a_out,
                                                           u64 *__restrict__ b_out, u32 *__restrict__ c_out, u64 n,
                                                           int shift, u32 mask, const u32 *__restrict__ tile_off, u32 xg, u32 dmode, u32 world,
-                                                          u32 fmode, u32 fme)
+                                                          u32 fmode, u32 fme, unsigned char *__restrict__ nd_out /* null, or: the next pass's digit of every
+                                                          record, from the digit word, at the record's place */, int nd_shift, u32 nd_mask)
 {
     // FILTER: the tile is read whole, but only the records whose owner (rs_digit with dmode = fmode) is `fme` are ranked,
     // staged and written -- the first pass of a sort over ALL records of a multi-GPU build that keeps this rank's
@@ -314,6 +343,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter(const u64 *__restrict__ a_
             const u64 v = stage[i];
             dst[k] = delta[rs_digit(v, shift, mask, dmode, world)] + i;
             dig_out[dst[k]] = v;
+            if (nd_out) nd_out[dst[k]] = (unsigned char)((u32)(v >> nd_shift) & nd_mask);
         }
     }
     if (HAS_B) {
@@ -376,6 +406,18 @@ int SortScratch::reserve(u64 n)
     return 0;
 }
 
+int SortScratch::reserve_next_digit(u64 n)
+{
+    if (external) return (int)hipErrorInvalidValue;
+    if (n <= cap_next_digit) return 0;
+    if (next_digit) (void)hipFree(next_digit);
+    next_digit = nullptr; cap_next_digit = 0;
+    const size_t want = (size_t)n + (size_t)(n / 8) + 4096;
+    RS_CHECK(hipMalloc(&next_digit, want));
+    cap_next_digit = want;
+    return 0;
+}
+
 void SortScratch::bind_external(u32 *hist, size_t tiles, u32 *chunks, size_t chunk_count)
 {
     release();
@@ -388,36 +430,40 @@ void SortScratch::release()
 {
     if (tile_hist && !external) (void)hipFree(tile_hist);
     if (chunk_sums && !external) (void)hipFree(chunk_sums);
+    if (next_digit) (void)hipFree(next_digit);
+    next_digit = nullptr; cap_next_digit = 0;
     external = false;
     if (ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
     tile_hist = nullptr; chunk_sums = nullptr; cap_tiles = cap_chunks = 0;
 }
 
+struct NextDigit { unsigned char *out = nullptr; int shift = 0; u32 mask = 0; };
 template <bool HAS_B, bool HAS_C>
 static void launch_scatter(hipStream_t s, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
-                           int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0, u32 fmode = 0, u32 fme = 0)
+                           int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode, u32 world, u32 fmode, u32 fme, const NextDigit &nd)
 {
     constexpr int T = (HAS_C || HAS_B) ? 512 : 256;
     if (fmode)                              // (the filtered first pass of a sort: the digit word is a)
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T, true>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, fmode, fme, nd.out, nd.shift, nd.mask);
     else if (HAS_B && dig_b)
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, true, T, false>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg, dmode, world, 0u, 0u);
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, 0u, 0u, nd.out, nd.shift, nd.mask);
     else
         hipLaunchKernelGGL((rs_scatter<HAS_B, HAS_C, false, T, false>), dim3(tiles), dim3(T), 0, s, in.a, in.b, in.c, out.a, out.b,
-                           out.c, n, shift, mask, tile_off, xg, dmode, world, 0u, 0u);
+                           out.c, n, shift, mask, tile_off, xg, dmode, world, 0u, 0u, nd.out, nd.shift, nd.mask);
 }
 
 static void launch_scatter_any(hipStream_t s, bool has_b, bool has_c, bool dig_b, u32 tiles, const SortArrays &in, const SortArrays &out, u64 n,
-                               int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0, u32 fmode = 0, u32 fme = 0)
+                               int shift, u32 mask, const u32 *tile_off, u32 xg, u32 dmode = 0, u32 world = 0, u32 fmode = 0, u32 fme = 0,
+                               const NextDigit &nd = NextDigit())
 {
     if (has_b) {
-        if (has_c) launch_scatter<true, true>(s, dig_b, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
-        else launch_scatter<true, false>(s, dig_b, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+        if (has_c) launch_scatter<true, true>(s, dig_b, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme, nd);
+        else launch_scatter<true, false>(s, dig_b, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme, nd);
     } else {
-        if (has_c) launch_scatter<false, true>(s, false, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
-        else launch_scatter<false, false>(s, false, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme);
+        if (has_c) launch_scatter<false, true>(s, false, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme, nd);
+        else launch_scatter<false, false>(s, false, tiles, in, out, n, shift, mask, tile_off, xg, dmode, world, fmode, fme, nd);
     }
 }
 
@@ -426,6 +472,12 @@ static void launch_hist(hipStream_t s, bool wide, u32 tiles, const u64 *word, u6
 {
     if (wide) hipLaunchKernelGGL(rs_hist<512>, dim3(tiles), dim3(512), 0, s, word, n, shift, mask, th, dmode, world, fmode, fme);
     else hipLaunchKernelGGL(rs_hist<256>, dim3(tiles), dim3(256), 0, s, word, n, shift, mask, th, dmode, world, fmode, fme);
+}
+
+static void launch_hist_bytes(hipStream_t s, bool wide, u32 tiles, const unsigned char *nd, u64 n, u32 *th)
+{
+    if (wide) hipLaunchKernelGGL(rs_hist_bytes<512>, dim3(tiles), dim3(512), 0, s, nd, n, th);
+    else hipLaunchKernelGGL(rs_hist_bytes<256>, dim3(tiles), dim3(256), 0, s, nd, n, th);
 }
 
 static void launch_offsets(hipStream_t s, u32 *th, u32 tiles, SortScratch &scratch, unsigned long long *grand_total = nullptr)
@@ -496,6 +548,13 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     // on the build): a pass that writes the second word ABOVE the array it reads it from takes 17.6-19.5 ms, one that writes it
     // below 19.6-21.9 ms; where the first word goes makes no difference.  A ping-pong has one pass of each kind in turn.  With
     // keys.b the first of a chain of arrays every pass writes into the next one up, and only the step back to the first goes down.
+    // The next digit travels ahead.  A histogram pass reads the key word of every record (8 bytes, 4.3 ms at 2.9e9 records) for
+    // one byte of it.  The scatter before it has that word in its hands: it writes the NEXT pass's digit of every record, one byte, at the
+    // record's new place (runs of bytes as long as the runs of records), and the next histogram reads those bytes.  Only between
+    // passes whose digits come from the same word, for sorts large enough to care, and not with a caller's scratch (no room).
+    static const bool nd_env = !(getenv("RS_NEXT_DIGIT") && atoi(getenv("RS_NEXT_DIGIT")) == 0);
+    const bool nd_ok = nd_env && !scratch.external && n >= (1u << 16) && scratch.reserve_next_digit(n) == 0;
+    bool have_nd = false;                                           // scratch.next_digit holds this pass's digits
     u64 *const chain = (has_b && keys.b_chain_n > 1) ? keys.b : nullptr;
     const int chain_n = chain ? keys.b_chain_n : 0;
     const size_t chain_stride = keys.b_stride;
@@ -507,26 +566,34 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
         const int shift = has_b ? (bit & 63) : bit;
         const u64 *word = dig_b ? keys.b : keys.a;
         u32 *th = scratch.tile_hist;
+        NextDigit nd;
+        if (nd_ok && bit + 8 < bit_hi && (has_b && bit + 8 < 64) == dig_b) {
+            const int nb2 = (bit_hi - bit - 8) < 8 ? (bit_hi - bit - 8) : 8;
+            nd.out = scratch.next_digit; nd.shift = has_b ? ((bit + 8) & 63) : bit + 8; nd.mask = (1u << nb2) - 1u;
+        }
         if (pass == 0 && from) {
             // the kept records' offsets are in scratch.tile_hist already (radix_sort_count_kept, same bit range); the pass reads
             // the whole source and writes this rank's records, so what follows works on n records
             const u32 tiles0 = (u32)((from->n + tile_recs - 1) / tile_recs);
             if (chain) { chain_at = (chain_at + 1) % chain_n; tmp.b = chain + (size_t)chain_at * chain_stride; }      // (keys.b, the chain's first array, is not read by this pass)
             if (timed) RS_CHECK(hipEventRecord(scratch.ev[0], s));
-            launch_scatter_any(s, has_b, has_c, false, tiles0, from->src, tmp, from->n, shift, mask, th, scratch.xcd_group, 0u, from->world, (u32)from->fmode, from->me);
+            launch_scatter_any(s, has_b, has_c, false, tiles0, from->src, tmp, from->n, shift, mask, th, scratch.xcd_group, 0u, from->world, (u32)from->fmode, from->me, nd);
             if (timed) RS_CHECK(hipEventRecord(scratch.ev[1], s));
-            moved[0] = rec_bytes * (from->n + n);
+            have_nd = nd.out != nullptr;
+            moved[0] = rec_bytes * (from->n + n) + (have_nd ? n : 0);
             SortArrays t0 = keys; keys = tmp; tmp = t0;
             continue;
         }
         if (pass == 0 && first_hist) th = first_hist;                    // the producer already counted this digit (tiles of radix_sort_tile_records())
+        else if (have_nd) launch_hist_bytes(s, has_c || has_b, tiles, scratch.next_digit, n, th);
         else launch_hist(s, has_c || has_b, tiles, word, n, shift, mask, th);
         launch_offsets(s, th, tiles, scratch);
         if (chain) { chain_at = (chain_at + 1) % chain_n; tmp.b = chain + (size_t)chain_at * chain_stride; }
         if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass], s));
-        launch_scatter_any(s, has_b, has_c, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group);
+        launch_scatter_any(s, has_b, has_c, dig_b, tiles, keys, tmp, n, shift, mask, th, scratch.xcd_group, 0u, 0u, 0u, 0u, nd);
         if (timed) RS_CHECK(hipEventRecord(scratch.ev[2 * pass + 1], s));
-        moved[pass] = 2 * rec_bytes * n;
+        have_nd = nd.out != nullptr;
+        moved[pass] = 2 * rec_bytes * n + (have_nd ? n : 0);          // (the digit bytes are part of what the pass writes)
         SortArrays t = keys; keys = tmp; tmp = t;
     }
     if (timed) {                                                   // read the events once, after the last pass

@@ -39,6 +39,11 @@ struct SortScratch {
     u32 xcd_group = 0;           // consecutive tiles handed to one XCD by the scatter (0 = not chosen yet)
     hipEvent_t ev[2 * 16] = {};  // one pair per pass of a sort (created when a sort is first timed)
     bool external = false;       // tile_hist / chunk_sums are the caller's memory: never grown, never freed
+    // [records] the NEXT pass's digit of every record, in output order, written by a scatter pass beside the records: the next pass's
+    // histogram then reads one byte per record instead of the key word (radix_sort.hip, "the next digit travels ahead")
+    unsigned char *next_digit = nullptr;
+    size_t cap_next_digit = 0;
+    int reserve_next_digit(u64 n);
     int reserve(u64 n);
     void release();
     // Use caller-owned device memory instead of hipMalloc: hist holds tiles * 256 u32, chunks 2 * chunk_count * 256 u32.
