@@ -318,7 +318,7 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         job->packed_in_flight = true;
     }
     ExactLocal x;
-    RCQ(st_kmers(job, 0, (u32)((dp.G + 255) / 256), x.rec, x.gp, x.N));
+    RCQ(st_kmers(job, 0, (u32)((dp.G + 255) / 256), x.rec, x.gp, x.N, &x.first_digit_ready));
     st.kmers = x.N;
     HIPQ(hipEventRecord(job->ev[1], s));
     // every contig must own at least one window (else the reference reads before its buffer, HTS:2530)

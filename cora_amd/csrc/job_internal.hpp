@@ -306,6 +306,7 @@ struct ExactLocal {                  // device results of class detection over o
     DBuf<u32> nonrep;                // [n_words] later members of this rank's classes (every valid window not in here is a representative)
     DBuf<u64> cls;                   // [NNS] rep<<32 | index of the first record, classes with >= 2 entries
     u64 N = 0, NR = 0, NNS = 0;
+    bool first_digit_ready = false;  // st_kmers left the records' first sort digit in the sort scratch (consumed by st_exact_classes)
     void release_all() { rec.release(); trec.release(); gp.release(); tgp.release(); cls_m.release(); nonrep.release(); cls.release(); rec_s = nullptr; gp_s = nullptr; }
 };
 struct ExactParts {                  // entry lists of classes, ent laid out in the order of cls
@@ -321,7 +322,7 @@ struct PairStore {
 };
 
 int st_pack(cora_hip_job *job);
-int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out);
+int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out, bool *first_digit_ready = nullptr);
 int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from = nullptr);
 inline int exact_sort_bits(const cora_hip_job *job) { return job->hash_bits ? job->hash_bits : 40; }     // the exact sort runs on the top bits of the hash
 // A seed sort of many records leaves the last code byte to the candidate kernels, which order every bucket of equal top 24 bits in

@@ -346,7 +346,9 @@ __device__ __forceinline__ void canonical_at(const DevParams &p, const u64 *__re
 // equal keys have equal hashes, and k_same_detect / k_mixed_fix make the grouping exact.
 __global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64 *__restrict__ pk, const u32 *__restrict__ valid,
                                                           const u64 *__restrict__ block_off, u64 *__restrict__ rec,
-                                                          u32 *__restrict__ gpos)
+                                                          u32 *__restrict__ gpos, unsigned char *__restrict__ first_digit /* null, or: byte fd_shift / 8
+                                                          of every record, for the first histogram of its sort (radix_sort.hip, SortScratch::next_digit) */,
+                                                          int fd_shift)
 {
     __shared__ u32 wsum[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(256) void k_kmer_emit_hashed(DevParams p, const u64
     const u64 h = (fl & 1u) ? key_hash(rhi, rlo) : key_hash(hi, lo);
     rec[at] = (h & ~0xFFull) | fl;
     gpos[at] = (u32)g;
+    if (first_digit) first_digit[at] = (unsigned char)(h >> fd_shift);
 }
 
 // After the sort on the top `hb` hash bits: head_flag[i] = 1 when record i opens a class.  Records with
@@ -3180,12 +3183,12 @@ void launch_test_window_bits(hipStream_t s, const DevParams &p, const u32 *bad, 
     hipLaunchKernelGGL(k_test_window_bits, grid_for(p.n_words), dim3(256), 0, s, p, bad, fast, slow);
 }
 void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *valid, const u64 *block_off, u32 block_lo,
-                                   u32 n_blocks, u64 *rec, u32 *gpos)
+                                   u32 n_blocks, u64 *rec, u32 *gpos, unsigned char *first_digit, int fd_shift)
 {
     if (!n_blocks) return;
     DevParams q = p;
     q.pos_base = (u64)block_lo * 256;
-    hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, q, pk, valid, block_off, rec, gpos);
+    hipLaunchKernelGGL(k_kmer_emit_hashed, dim3(n_blocks), dim3(256), 0, s, q, pk, valid, block_off, rec, gpos, first_digit, fd_shift);
 }
 }  // namespace cora
 

@@ -194,7 +194,9 @@ void launch_count_dest(hipStream_t s, const u64 *dest, u64 n, u32 world, unsigne
 void launch_kmer_count_range(hipStream_t s, const DevParams &p, const u32 *bad, u32 *block_counts, u32 block_lo, u32 n_blocks,
                              u32 *valid /* window-validity bitmap, written for the blocks of the range */);
 void launch_kmer_emit_hashed_range(hipStream_t s, const DevParams &p, const u64 *pk, const u32 *valid, const u64 *block_off,
-                                   u32 block_lo, u32 n_blocks, u64 *rec, u32 *gpos);
+                                   u32 block_lo, u32 n_blocks, u64 *rec, u32 *gpos,
+                                   unsigned char *first_digit = nullptr /* [records] byte fd_shift / 8 of every record (the first histogram of its sort reads it) */,
+                                   int fd_shift = 0);
 }  // namespace cora
 
 namespace cora {

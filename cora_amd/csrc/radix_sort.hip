@@ -520,8 +520,14 @@ int radix_sort_count_kept(hipStream_t s, const SortSource &from, int bit_lo, int
     return 0;
 }
 
+bool radix_sort_next_digit_wanted(const SortScratch &scratch, u64 n)
+{
+    static const bool nd_env = !(getenv("RS_NEXT_DIGIT") && atoi(getenv("RS_NEXT_DIGIT")) == 0);
+    return nd_env && !scratch.external && n >= (1u << 16);
+}
+
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi, SortScratch &scratch,
-               SortTiming *timing, u32 *first_hist, const SortSource *from)
+               SortTiming *timing, u32 *first_hist, const SortSource *from, bool first_digits_ready)
 {
     if (n == 0 || bit_hi <= bit_lo) return 0;
     if (n >= (1ull << 32)) return (int)hipErrorInvalidValue;      // u32 offsets inside the kernels
@@ -552,9 +558,8 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     // one byte of it.  The scatter before it has that word in its hands: it writes the NEXT pass's digit of every record, one byte, at the
     // record's new place (runs of bytes as long as the runs of records), and the next histogram reads those bytes.  Only between
     // passes whose digits come from the same word, for sorts large enough to care, and not with a caller's scratch (no room).
-    static const bool nd_env = !(getenv("RS_NEXT_DIGIT") && atoi(getenv("RS_NEXT_DIGIT")) == 0);
-    const bool nd_ok = nd_env && !scratch.external && n >= (1u << 16) && scratch.reserve_next_digit(n) == 0;
-    bool have_nd = false;                                           // scratch.next_digit holds this pass's digits
+    const bool nd_ok = radix_sort_next_digit_wanted(scratch, n) && scratch.reserve_next_digit(n) == 0;
+    bool have_nd = nd_ok && first_digits_ready && !from && !first_hist;      // scratch.next_digit holds this pass's digits
     u64 *const chain = (has_b && keys.b_chain_n > 1) ? keys.b : nullptr;
     const int chain_n = chain ? keys.b_chain_n : 0;
     const size_t chain_stride = keys.b_stride;

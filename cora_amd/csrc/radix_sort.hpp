@@ -78,8 +78,12 @@ struct SortSource {
     u32 world = 1, me = 0;
 };
 int radix_sort_count_kept(hipStream_t s, const SortSource &from, int bit_lo, int bit_hi, SortScratch &scratch, u64 *n_kept);
+// first_digits_ready: the producer of the records has left the first pass's digit of every record in scratch.next_digit (asked
+// radix_sort_next_digit_wanted first, reserved with reserve_next_digit): the first histogram reads those bytes.
+bool radix_sort_next_digit_wanted(const SortScratch &scratch, u64 n);
 int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_lo, int bit_hi,
-               SortScratch &scratch, SortTiming *timing, u32 *first_hist = nullptr, const SortSource *from = nullptr);
+               SortScratch &scratch, SortTiming *timing, u32 *first_hist = nullptr, const SortSource *from = nullptr,
+               bool first_digits_ready = false);
 
 // out[i] = sum_{j<i} in[j]  (u32 in, u64 out); *total_dev (device u64) gets the grand total.
 // scratch_dev must hold at least scan_scratch_elems(n) u64.

@@ -16,7 +16,9 @@ int st_pack(cora_hip_job *job)
 }
 
 // hashed records (hash|flags, gpos) of the valid windows of blocks [block_lo, block_lo + n_blocks) of 256 positions
-int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out)
+// first_digit_ready (optional): the records' first sort digit (exact_sort_bits) has been left in job->sort_scratch.next_digit for the
+// sort that follows at once (st_exact_classes without `from`): its first histogram then reads bytes (radix_sort.hip).
+int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf<u32> &gp, u64 &n_out, bool *first_digit_ready)
 {
     const DevParams &dp = job->dp;
     hipStream_t s = job->stream;
@@ -30,7 +32,13 @@ int st_kmers(cora_hip_job *job, u32 block_lo, u32 n_blocks, DBuf<u64> &rec, DBuf
     HIPQ(hipStreamSynchronize(s));
     n_out = n;
     RCQ(rec.alloc(n)); RCQ(gp.alloc(n));
-    launch_kmer_emit_hashed_range(s, dp, job->pk.p, job->valid.p, boff.p, block_lo, n_blocks, rec.p, gp.p);
+    unsigned char *fd = nullptr;
+    const int fd_shift = (64 - exact_sort_bits(job)) & ~7;
+    if (first_digit_ready) {
+        *first_digit_ready = false;
+        if (radix_sort_next_digit_wanted(job->sort_scratch, n) && job->sort_scratch.reserve_next_digit(n) == 0) { fd = job->sort_scratch.next_digit; *first_digit_ready = true; }
+    }
+    launch_kmer_emit_hashed_range(s, dp, job->pk.p, job->valid.p, boff.p, block_lo, n_blocks, rec.p, gp.p, fd, fd_shift);
     HIPQ(hipStreamSynchronize(s));
     return 0;
 }
@@ -58,7 +66,8 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from)
     const int hb = exact_sort_bits(job);
     SortArrays keys, tmp;
     keys.a = x.rec.p; keys.c = x.gp.p; tmp.a = x.trec.p; tmp.c = x.tgp.p;
-    if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing, nullptr, from)) return fail(100, "radix sort failed");
+    if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing, nullptr, from, !from && x.first_digit_ready)) return fail(100, "radix sort failed");
+    x.first_digit_ready = false;
     DevCounters h;
     ZERO_COUNTERS(job, n_mixed, 2);                              // n_mixed, fallback
     {
