@@ -394,8 +394,12 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         SortArrays kk, kt;
         kk.a = ik.p; kk.c = im.p; kt.a = ik_tmp.p; kt.c = im_tmp.p;
         const int gb = bits_for(dp.G);
-        if (radix_sort(s, kk, kt, M, 0, gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
-        if (radix_sort(s, kk, kt, M, 32, 32 + gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+        if (gb == 32) {                                     // (target then source = all 64 bits: one sort, no histogram of key words in between)
+            if (radix_sort(s, kk, kt, M, 0, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+        } else {
+            if (radix_sort(s, kk, kt, M, 0, gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+            if (radix_sort(s, kk, kt, M, 32, 32 + gb, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
+        }
         trace_mark(job, "items: two sorts", 2);
         const u64 item_words = (M + 63) / 64;               // list heads as a mask: one word per 64 items
         DBuf<u64> head_mask;
