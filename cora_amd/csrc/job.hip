@@ -317,6 +317,8 @@ extern "C" int cora_hip_job_run(cora_hip_job *job)
         HIPQ(hipEventRecord(job->ev_copy[EV_PACKED_ARRIVED], job->copy_stream));
         job->packed_in_flight = true;
     }
+    // (the digit bytes of every sort of this run, lent to the sort scratch from the pool: no sort here holds more than G records)
+    NextDigitLease digit_bytes(job->sort_scratch, dp.G);
     ExactLocal x;
     RCQ(st_kmers(job, 0, (u32)((dp.G + 255) / 256), x.rec, x.gp, x.N, &x.first_digit_ready));
     st.kmers = x.N;

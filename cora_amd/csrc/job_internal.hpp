@@ -180,6 +180,23 @@ struct HBuf {
     ~HBuf() { if (p) (void)hipHostFree(p); }
 };
 
+// Lends the sort scratch pool memory for its digit bytes (radix_sort.hip, "the next digit travels ahead") while sorts of up to n records
+// run; a lease inside another one does nothing.  Without room in the pool the sorts read key words for their histograms, as before.
+struct NextDigitLease {
+    SortScratch &sc;
+    DBuf<u8> buf;
+    bool mine = false;
+    NextDigitLease(SortScratch &scratch, u64 n) : sc(scratch)
+    {
+        if (sc.lease_next_digit || !radix_sort_next_digit_wanted(sc, n)) return;
+        if (buf.alloc(n)) { (void)hipGetLastError(); return; }
+        sc.lease_next_digit = buf.p; sc.cap_lease_next_digit = (size_t)n; mine = true;
+    }
+    ~NextDigitLease() { if (mine) { sc.lease_next_digit = nullptr; sc.cap_lease_next_digit = 0; sc.next_digit = sc.own_next_digit; } }
+    NextDigitLease(const NextDigitLease &) = delete;
+    NextDigitLease &operator=(const NextDigitLease &) = delete;
+};
+
 struct PoolScope {                                       // binds a job's pool to the calling thread for one API call
     DevPool *prev;
     explicit PoolScope(DevPool *p) : prev(g_pool) { g_pool = p; }

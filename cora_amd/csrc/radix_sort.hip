@@ -409,12 +409,16 @@ int SortScratch::reserve(u64 n)
 int SortScratch::reserve_next_digit(u64 n)
 {
     if (external) return (int)hipErrorInvalidValue;
-    if (n <= cap_next_digit) return 0;
-    if (next_digit) (void)hipFree(next_digit);
-    next_digit = nullptr; cap_next_digit = 0;
-    const size_t want = (size_t)n + (size_t)(n / 8) + 4096;
-    RS_CHECK(hipMalloc(&next_digit, want));
-    cap_next_digit = want;
+    if (lease_next_digit && n <= cap_lease_next_digit) { next_digit = lease_next_digit; return 0; }
+    if (n > RS_OWN_NEXT_DIGIT_MAX) return (int)hipErrorOutOfMemory;          // (no lease for a sort this large: key-word histograms)
+    if (n > cap_own_next_digit) {
+        if (own_next_digit) (void)hipFree(own_next_digit);
+        own_next_digit = nullptr; cap_own_next_digit = 0;
+        const size_t want = (size_t)n + (size_t)(n / 8) + 4096;
+        RS_CHECK(hipMalloc(&own_next_digit, want));
+        cap_own_next_digit = want;
+    }
+    next_digit = own_next_digit;
     return 0;
 }
 
@@ -430,8 +434,8 @@ void SortScratch::release()
 {
     if (tile_hist && !external) (void)hipFree(tile_hist);
     if (chunk_sums && !external) (void)hipFree(chunk_sums);
-    if (next_digit) (void)hipFree(next_digit);
-    next_digit = nullptr; cap_next_digit = 0;
+    if (own_next_digit) (void)hipFree(own_next_digit);
+    own_next_digit = next_digit = nullptr; cap_own_next_digit = 0;
     external = false;
     if (ev[0]) for (int i = 0; i < 2 * RS_MAX_PASSES; i++) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
     tile_hist = nullptr; chunk_sums = nullptr; cap_tiles = cap_chunks = 0;

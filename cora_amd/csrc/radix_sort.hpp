@@ -41,8 +41,11 @@ struct SortScratch {
     bool external = false;       // tile_hist / chunk_sums are the caller's memory: never grown, never freed
     // [records] the NEXT pass's digit of every record, in output order, written by a scatter pass beside the records: the next pass's
     // histogram then reads one byte per record instead of the key word (radix_sort.hip, "the next digit travels ahead")
-    unsigned char *next_digit = nullptr;
-    size_t cap_next_digit = 0;
+    unsigned char *next_digit = nullptr;      // what the sort at hand uses: the lease if one is bound and large enough, else the scratch's own array
+    unsigned char *own_next_digit = nullptr;  // grown with hipMalloc on demand, up to RS_OWN_NEXT_DIGIT_MAX records (beyond: no digit bytes, key-word histograms)
+    size_t cap_own_next_digit = 0;
+    unsigned char *lease_next_digit = nullptr;   // caller's memory for the time of some sorts (a job lends pool memory: a separate 3 GB hipMalloc
+    size_t cap_lease_next_digit = 0;             // made a process 50 ms slower to end)
     int reserve_next_digit(u64 n);
     int reserve(u64 n);
     void release();
@@ -55,6 +58,7 @@ constexpr int RS_THREADS = 256;                   // smallest workgroup of the s
 constexpr int RS_IPT = 16;
 constexpr int RS_TILE_MIN = RS_THREADS * RS_IPT;  // 4096 records: the smallest tile
 constexpr int RS_CHUNK_TILES = 64;                // tiles per column-scan workgroup
+constexpr size_t RS_OWN_NEXT_DIGIT_MAX = (size_t)1 << 28;
 
 // Sorts n records by key bits [bit_lo, bit_hi) (bit 0 = LSB of the logical key,
 // bit_lo is rounded down to a multiple of 8).  Stable.  `keys` and `tmp` are

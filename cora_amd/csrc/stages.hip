@@ -64,6 +64,7 @@ int st_exact_classes(cora_hip_job *job, ExactLocal &x, const SortSource *from)
     // About N^2 / 2^(hb+1) pairs of different K-mers collide: a thousand at 64 M records, 2e6 at 3e9 -- repaired in 3 ms,
     // where a sixth pass over 3e9 records costs 20 (48 bits: CORA_HASH_BITS=48).
     const int hb = exact_sort_bits(job);
+    NextDigitLease digit_bytes(job->sort_scratch, N);         // (does nothing inside the single-GPU run's own lease)
     SortArrays keys, tmp;
     keys.a = x.rec.p; keys.c = x.gp.p; tmp.a = x.trec.p; tmp.c = x.tgp.p;
     if (radix_sort(s, keys, tmp, N, 64 - hb, 64, job->sort_scratch, &job->sort_timing, nullptr, from, !from && x.first_digit_ready)) return fail(100, "radix sort failed");
@@ -270,6 +271,7 @@ int st_seed_verify(cora_hip_job *job, DBuf<u64> &codes, u64 n, int seed, PairSto
     if (sk_c) { RCQ(skc_tmp.alloc(n)); ck.c = sk_c; ct.c = skc_tmp.p; }
     // the records are a (code << 32 | position); with a b array the sort's logical key is a:b, i.e. a's bits sit 64 higher
     const int key_lo = seed_sort_lo(sk_b != nullptr, lds), key_hi = seed_sort_hi(sk_b != nullptr);
+    NextDigitLease digit_bytes(job->sort_scratch, n);
     if (radix_sort(s, ck, ct, n, key_lo, key_hi, job->sort_scratch, &job->sort_timing, first_hist, from)) return fail(100, "radix sort failed");
     // lds: the records are now sorted on the top 24 code bits; the candidate kernels order the rest in LDS
     const u64 ab = lds ? verify_blocks_ps(n) : verify_blocks(n);  // workgroups (tiles) of the candidate kernels
@@ -394,6 +396,7 @@ int st_items_finish(cora_hip_job *job, DBuf<u64> &ik, DBuf<u32> &im, u64 M, Fini
         SortArrays kk, kt;
         kk.a = ik.p; kk.c = im.p; kt.a = ik_tmp.p; kt.c = im_tmp.p;
         const int gb = bits_for(dp.G);
+        NextDigitLease digit_bytes(job->sort_scratch, M);
         if (gb == 32) {                                     // (target then source = all 64 bits: one sort, no histogram of key words in between)
             if (radix_sort(s, kk, kt, M, 0, 64, job->sort_scratch, &job->sort_timing)) return fail(100, "radix sort failed");
         } else {
