@@ -209,7 +209,9 @@ void reserve_job_arena(cora_hip_job *job, int world, bool keep_own)
     if (share > 1 && (room > free_b || room < ((size_t)8 << 30))) return;
     if (want > room) want = room;
     const auto a0 = std::chrono::steady_clock::now();
-    const bool ok = job->pool.reserve_arena(want);
+    // (the digit bytes of the sorts, one per record of the largest sort, in the allocation's tail: DevPool::tail)
+    const size_t digit_bytes = (size_t)dp.G / (size_t)world + (size_t)dp.G / 8 + ((size_t)4 << 20);
+    const bool ok = job->pool.reserve_arena(want, digit_bytes);
     if (ok) job->arena_world = world;
     if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] arena: hipMalloc took %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
     if (getenv("CORA_TRACE")) fprintf(stderr, "[cora] arena of %.1f GB (%d rank(s)): %s\n", want / 1073741824.0, world, ok ? "reserved" : "not available, separate blocks");
