@@ -562,9 +562,7 @@ int radix_sort(hipStream_t s, SortArrays &keys, SortArrays &tmp, u64 n, int bit_
     // one byte of it.  The scatter before it has that word in its hands: it writes the NEXT pass's digit of every record, one byte, at the
     // record's new place (runs of bytes as long as the runs of records), and the next histogram reads those bytes.  Only between
     // passes whose digits come from the same word, for sorts large enough to care, and not with a caller's scratch (no room).
-    // (not for 20-byte records, two words + payload: their scatter, short of registers as it is, lost 4 ms per pass of 2.9e9 records
-    //  to the byte stores -- K = 64, d = 3 at 3.09 Gbp: seeds stage 621 against 609 ms -- where a key-word histogram costs 4.3)
-    const bool nd_ok = !(has_b && has_c) && radix_sort_next_digit_wanted(scratch, n) && scratch.reserve_next_digit(n) == 0;
+    const bool nd_ok = radix_sort_next_digit_wanted(scratch, n) && scratch.reserve_next_digit(n) == 0;
     bool have_nd = nd_ok && first_digits_ready && !from && !first_hist;      // scratch.next_digit holds this pass's digits
     u64 *const chain = (has_b && keys.b_chain_n > 1) ? keys.b : nullptr;
     const int chain_n = chain ? keys.b_chain_n : 0;
