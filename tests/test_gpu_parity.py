@@ -204,6 +204,20 @@ def test_executable_with_either_seed_sort(name, seed_sort, tmp_path):
     helpers.assert_same_tables(ex, inx, want, name)
 
 
+@pytest.mark.parametrize("name", ["ecoli_like_k50_d2", "fam_k48_d3"])
+def test_histograms_from_key_words_give_the_same_tables(name, tmp_path, monkeypatch):
+    """From 65 536 records on a scatter pass of the sort leaves the next pass's digit of every record as a byte, and the next histogram reads
+    those bytes (radix_sort.hip, "the next digit travels ahead"): what every other test runs.  RS_NEXT_DIGIT=0 (read once per process, hence
+    the executable) makes the histograms read the key words as before round 3: same tables."""
+    c, want = helpers.golden_case(name)
+    exe = os.path.join(hip.BIN_DIR, "homTable_setup_L" if c["L"] else "homTable_setup")
+    monkeypatch.setenv("RS_NEXT_DIGIT", "0")
+    ex, inx, r = helpers.run_tool(exe, helpers.input_path(c["input"]), c["K"], c["d"], helpers.split_path("phys", c["p"]),
+                                  helpers.split_path("par", c["t"]), str(tmp_path / "out"))
+    assert r.returncode == 0, r.stdout
+    helpers.assert_same_tables(ex, inx, want, name)
+
+
 def test_executable_is_a_drop_in(tmp_path):
     name = "syn_k47_d2_L"
     c, want = helpers.golden_case(name)
