@@ -1576,6 +1576,7 @@ constexpr int PS_R = PS_TILE + PS_OVER + 2;          // 2304 LDS slots of the ba
 constexpr int PS_PER = PS_R / 256;                   // 9 slots per thread
 constexpr int PS_WAVE = PS_R / 4;                    // 576 per wave
 constexpr int PS_MAXB = 512;                         // a bucket is sorted in at most 8 rounds of 64
+constexpr int PS_STRIP = 2 * VP_STRIP;                 // pair places per pass of k_candidates_pairs_ps's strip (16-bit markers in the same LDS)
 constexpr int PS_WHALO = 256;                        // the walk keeps that many records before the tile as well
 constexpr int PS_WR = PS_WHALO + PS_TILE + PS_OVER + 2;      // 2560 slots: slot k + PS_WHALO = record base + k
 static_assert(PS_R % 256 == 0 && PS_WR % 256 == 0 && PS_R % 64 == 0, "tile geometry");
@@ -1823,21 +1824,27 @@ __global__ __launch_bounds__(256) void k_candidates_pairs_ps(DevParams p, const 
     const u64 lt_mask = (1ull << lane) - 1ull;
     u32 wslots = 0, carry_o = 0, carry_P = 0;
     bool spill = false;
-    u32 *mk = s_mk[wv];
+    // The strip of k_candidates_pairs with 16-bit markers, so that the wave's 512 bytes hold PS_STRIP = 256 places instead of 128 (every
+    // strip costs a pass over the lane's PS_PER records): a marker is its record's index + 1, and WHERE it sits is its P -- the max-scan
+    // runs over (place + 1) of the occupied places, and the owner's index is read from the strip at the place the scan returns.
+    typedef uint16_t __attribute__((may_alias)) marker_t;       // (the strip is cleared as words and read as halves)
+    marker_t *mk = reinterpret_cast<marker_t *>(s_mk[wv]);
+    u32 *mk32 = s_mk[wv];
     const EarlyWords early(p.sk_early);
-    for (u32 c0 = 0; c0 < W; c0 += VP_STRIP) {
+    for (u32 c0 = 0; c0 < W; c0 += PS_STRIP) {
 #pragma unroll
-        for (int x = 0; x < VP_STRIP / 64; x++) mk[x * 64 + lane] = 0;
+        for (int x = 0; x < PS_STRIP / 128; x++) mk32[x * 64 + lane] = 0;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < PS_PER; j++)
-            if (r[j] && pr[j] >= c0 && pr[j] < c0 + VP_STRIP) mk[pr[j] - c0] = ((u32)(PS_PER * lane + j + 1) << 16) | (pr[j] - c0);
+            if (r[j] && pr[j] - c0 < (u32)PS_STRIP) mk[pr[j] - c0] = (marker_t)(PS_PER * lane + j + 1);
         __builtin_amdgcn_wave_barrier();
-        for (u32 t = 0; t < VP_STRIP && c0 + t < W; t += 64) {
+        for (u32 t = 0; t < (u32)PS_STRIP && c0 + t < W; t += 64) {
             const u32 q = c0 + t + lane;
-            const u32 v = wave_scan_max(mk[t + lane]);
-            const u32 o_rec = v ? (v >> 16) - 1u : carry_o;
-            const u32 o_P = v ? c0 + (v & 0xFFFFu) : carry_P;
+            const u32 here = mk[t + lane];
+            const u32 v = wave_scan_max(here ? t + lane + 1u : 0u);          // place + 1 of the last marker at or before this lane's place; 0: none in this round
+            const u32 o_rec = v ? (u32)mk[v - 1u] - 1u : carry_o;
+            const u32 o_P = v ? c0 + v - 1u : carry_P;
             carry_o = (u32)__builtin_amdgcn_readlane((int)o_rec, 63); carry_P = (u32)__builtin_amdgcn_readlane((int)o_P, 63);
             bool pass = false;
             int li = 0, lj = 0;
