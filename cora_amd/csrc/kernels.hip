@@ -1380,7 +1380,8 @@ __device__ __forceinline__ u32 wave_scan_add(u32 v)
 //   3. the sketch test, and a slot for what passes, ranked by (wave, q): the order of the slots does not depend on timing.
 // Tiles this cannot do -- a palindromic code (HTS:2769-2792: other slot kinds), a run that may go on before the LDS copy --
 // are left to k_candidates (blk_mode 0); k_candidates skips the others.
-constexpr int VP_STRIP = 128;
+constexpr int VP_STRIP = 128;                          // u32 words of a wave's strip
+constexpr int PS_STRIP = 2 * VP_STRIP;                 // pair places per pass over the strip: 16-bit markers
 template <bool WRITE, bool SKB, bool SKC>
 __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64 *__restrict__ codes, u64 n, u32 *__restrict__ cnt_slots /* [blocks * 256] */,
                                                           u32 *__restrict__ blk_slots, u64 *__restrict__ blk_cand, const u64 *__restrict__ blk_off,
@@ -1489,21 +1490,26 @@ __global__ __launch_bounds__(256) void k_candidates_pairs(DevParams p, const u64
     const u64 lt_mask = (1ull << lane) - 1ull;
     u32 wslots = 0, carry_o = 0, carry_P = 0;
     bool spill = false;
-    u32 *mk = s_mk[wv];
+    // (16-bit markers: 256 pair places per pass of the strip in the wave's 512 bytes; a marker's place is its P, its value the record's
+    //  index + 1 -- see k_candidates_pairs_ps)
+    typedef uint16_t __attribute__((may_alias)) marker_t;
+    marker_t *mk = reinterpret_cast<marker_t *>(s_mk[wv]);
+    u32 *mk32 = s_mk[wv];
     const EarlyWords early(p.sk_early);
-    for (u32 c0 = 0; c0 < W; c0 += VP_STRIP) {
+    for (u32 c0 = 0; c0 < W; c0 += PS_STRIP) {
 #pragma unroll
-        for (int x = 0; x < VP_STRIP / 64; x++) mk[x * 64 + lane] = 0;
+        for (int x = 0; x < PS_STRIP / 128; x++) mk32[x * 64 + lane] = 0;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (r[j] && pr[j] >= c0 && pr[j] < c0 + VP_STRIP) mk[pr[j] - c0] = ((u32)(8 * lane + j + 1) << 16) | (pr[j] - c0);
+            if (r[j] && pr[j] - c0 < (u32)PS_STRIP) mk[pr[j] - c0] = (marker_t)(8 * lane + j + 1);
         __builtin_amdgcn_wave_barrier();
-        for (u32 t = 0; t < VP_STRIP && c0 + t < W; t += 64) {
+        for (u32 t = 0; t < (u32)PS_STRIP && c0 + t < W; t += 64) {
             const u32 q = c0 + t + lane;
-            const u32 v = wave_scan_max(mk[t + lane]);
-            const u32 o_rec = v ? (v >> 16) - 1u : carry_o;
-            const u32 o_P = v ? c0 + (v & 0xFFFFu) : carry_P;
+            const u32 here = mk[t + lane];
+            const u32 v = wave_scan_max(here ? t + lane + 1u : 0u);          // place + 1 of the last marker at or before this lane's place; 0: none in this round
+            const u32 o_rec = v ? (u32)mk[v - 1u] - 1u : carry_o;
+            const u32 o_P = v ? c0 + v - 1u : carry_P;
             carry_o = (u32)__builtin_amdgcn_readlane((int)o_rec, 63); carry_P = (u32)__builtin_amdgcn_readlane((int)o_P, 63);
             bool pass = false;
             int li = 0, lj = 0;
@@ -1576,7 +1582,6 @@ constexpr int PS_R = PS_TILE + PS_OVER + 2;          // 2304 LDS slots of the ba
 constexpr int PS_PER = PS_R / 256;                   // 9 slots per thread
 constexpr int PS_WAVE = PS_R / 4;                    // 576 per wave
 constexpr int PS_MAXB = 512;                         // a bucket is sorted in at most 8 rounds of 64
-constexpr int PS_STRIP = 2 * VP_STRIP;                 // pair places per pass of k_candidates_pairs_ps's strip (16-bit markers in the same LDS)
 constexpr int PS_WHALO = 256;                        // the walk keeps that many records before the tile as well
 constexpr int PS_WR = PS_WHALO + PS_TILE + PS_OVER + 2;      // 2560 slots: slot k + PS_WHALO = record base + k
 static_assert(PS_R % 256 == 0 && PS_WR % 256 == 0 && PS_R % 64 == 0, "tile geometry");
